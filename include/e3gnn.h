@@ -1,0 +1,125 @@
+/*
+ * e3gnn.h — C ABI of libe3gnn_hip.so, the MI355X (gfx950) implementation of the Scalable-E3-GNN
+ * hot path.  Plain pointers and sizes only; no torch / C++ types cross this boundary.
+ *
+ * Every entry point returns an int status (E3_OK == 0); nothing throws across the ABI and nothing
+ * allocates device memory behind the caller's back except the small per-plan tables created in
+ * e3_l1tp_plan_create.  All kernels are enqueued on the caller's hipStream_t (passed as void*),
+ * never synchronise, and are graph-capturable.
+ *
+ * Reference interface replaced (file:line in /root/reference/models/segnn/l1_tensor_prod.py):
+ *   e3_l1tp_plan_create   <- L1TensorProduct.__init__ irreps partition, masks, counts   (:13-77)
+ *   e3_l1tp_pack_weights  <- parameters + CG constants + norm buffers                   (:81-94,159-189)
+ *   e3_l1tp_forward       <- L1TensorProduct.forward                                    (:234-299)
+ *   e3_l1tp_backward      <- autograd of forward (reference relies on torch autograd)    (:234-299)
+ * Builder-defined stages of the pipeline (no reference code in the mount) are
+ * declared further below and say so.
+ */
+#ifndef E3GNN_H
+#define E3GNN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define E3GNN_ABI_VERSION 1
+
+/* status codes */
+enum {
+  E3_OK = 0,
+  E3_ERR_INVALID_ARG = 1,   /* null pointer, negative size, bad dtype ...                     */
+  E3_ERR_BAD_IRREPS = 2,    /* l > 1, lmax != 1, parity not +-1, negative multiplicity          */
+  E3_ERR_MISSING_WEIGHT = 3,/* an output class has columns but its weight pointer is NULL        */
+  E3_ERR_UNSUPPORTED = 4,   /* shape exceeds what the kernels were built for                    */
+  E3_ERR_HIP = 5,           /* a HIP runtime call failed; see e3_last_hip_error()              */
+  E3_ERR_NO_DEVICE = 6
+};
+
+/* element types of in1 / in2 / weights / norms / out (all the same in one call) */
+enum { E3_F32 = 0, E3_F64 = 1, E3_BF16 = 2 };
+
+/* class index used for the 4-element pointer arrays below: l0e, l0o, l1e, l1o */
+enum { E3_CLS_0E = 0, E3_CLS_0O = 1, E3_CLS_1E = 2, E3_CLS_1O = 3 };
+
+typedef struct e3_l1tp_plan e3_l1tp_plan;
+
+int         e3_abi_version(void);
+const char* e3_status_string(int status);
+const char* e3_last_hip_error(void);
+
+/*
+ * Plan = host+device description of one (in1_irreps -> out_irreps) tensor product with the fixed
+ * second operand 1x0e+1x1o (spherical harmonics of an edge vector).
+ * blocks: n x 3 int32, each (l, p, mul) with l in {0,1}, p in {+1,-1}, mul >= 0, in declaration
+ * order (irreps are NOT sorted or merged: the column layout follows the declaration, :28-36,57-65).
+ * Requires max l == 1 for both (the reference's asserts, :13-14).
+ */
+int e3_l1tp_plan_create(const int32_t* in1_blocks, int n_in1,
+                        const int32_t* out_blocks, int n_out,
+                        e3_l1tp_plan** plan);
+int e3_l1tp_plan_destroy(e3_l1tp_plan* plan);
+
+/* Shape queries (so a binding needs no second implementation of the bookkeeping). */
+int e3_l1tp_in1_dim(const e3_l1tp_plan* plan);
+int e3_l1tp_out_dim(const e3_l1tp_plan* plan);
+/* rows/cols of weight matrix `cls` exactly as the reference allocates it (:81-88); 0,0 if absent */
+int e3_l1tp_weight_shape(const e3_l1tp_plan* plan, int cls, int* rows, int* cols);
+/* length of norm buffer `cls` (:159-162) */
+int e3_l1tp_norm_len(const e3_l1tp_plan* plan, int cls);
+
+/*
+ * Packed weights: one device buffer holding the four weight matrices re-tiled for the MFMA
+ * kernel (K padded per irreps block, 32-column tiles, CG constants 1/sqrt3, 1/sqrt6 folded in)
+ * plus the per-output-column norm vector.  Size in bytes for a given dtype:
+ */
+int64_t e3_l1tp_packed_bytes(const e3_l1tp_plan* plan, int dtype);
+/*
+ * weights[cls], norms[cls]: device pointers of element type `dtype`, row-major contiguous, shapes
+ * per e3_l1tp_weight_shape / e3_l1tp_norm_len.  weights[cls] may be NULL only when the class has
+ * no output columns or no input rows.  norms may be NULL (module built without normalisation)
+ * or hold NULL entries for empty classes.  `packed` must hold e3_l1tp_packed_bytes().
+ */
+int e3_l1tp_pack_weights(const e3_l1tp_plan* plan,
+                         const void* const weights[4], const void* const norms[4],
+                         int dtype, void* packed, void* stream);
+
+/*
+ * out[b, :] = L1TP(in1[b, :], in2[b, :])   for b in [0, B)
+ *   in1 : [B, in1_dim]   row stride ld_in1 elements
+ *   in2 : [B, 4] = [Y0, Y1x, Y1y, Y1z], row stride ld_in2 elements; ld_in2 == 0 broadcasts row 0
+ *   out : [B, out_dim]   row stride ld_out; every column is written
+ * `kernel`: 0 = auto, 1 = force the generic kernel, 2 = force the MFMA kernel (E3_ERR_UNSUPPORTED
+ * if the plan / dtype cannot use it).
+ */
+int e3_l1tp_forward(const e3_l1tp_plan* plan,
+                    const void* in1, int64_t ld_in1,
+                    const void* in2, int64_t ld_in2,
+                    const void* packed,
+                    void* out, int64_t ld_out,
+                    int64_t B, int dtype, int kernel, void* stream);
+
+/*
+ * Gradients of sum(out * grad_out).  grad_in1 [B,in1_dim] and grad_in2 [B,4] are overwritten;
+ * grad_weights[cls] (same shapes as weights) are overwritten.  When in2 was broadcast
+ * (ld_in2 == 0) grad_in2 is a single row [1,4].  `workspace` must hold
+ * e3_l1tp_backward_workspace_bytes() bytes.  Any of grad_in1 / grad_in2 / grad_weights may be
+ * NULL to skip that gradient.
+ */
+int64_t e3_l1tp_backward_workspace_bytes(const e3_l1tp_plan* plan, int64_t B, int dtype);
+int e3_l1tp_backward(const e3_l1tp_plan* plan,
+                     const void* in1, int64_t ld_in1,
+                     const void* in2, int64_t ld_in2,
+                     const void* const weights[4], const void* const norms[4],
+                     const void* grad_out, int64_t ld_gout,
+                     void* grad_in1, int64_t ld_gin1,
+                     void* grad_in2,
+                     void* const grad_weights[4],
+                     void* workspace,
+                     int64_t B, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* E3GNN_H */

@@ -1,0 +1,94 @@
+"""ctypes binding of ``libe3gnn_hip.so`` (C ABI declared in ``include/e3gnn.h``).
+
+There is no fallback: if the shared library is missing or a call fails, a ``RuntimeError`` is raised.
+``torch`` is imported first so that the HIP runtime already mapped by PyTorch-ROCm
+(``libamdhip64.so``, same SONAME) is the one the library binds to — device pointers and streams then
+belong to a single runtime.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_int, c_int32, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libe3gnn_hip.so")
+
+E3_OK = 0
+E3_F32, E3_F64, E3_BF16 = 0, 1, 2
+CLS_NAMES = ("l0e", "l0o", "l1e", "l1o")
+
+_lib = None
+
+VoidP4 = c_void_p * 4
+
+# name -> (restype, argtypes); mirrors include/e3gnn.h one to one
+SIGNATURES = {
+    "e3_abi_version": (c_int, []),
+    "e3_status_string": (c_char_p, [c_int]),
+    "e3_last_hip_error": (c_char_p, []),
+    "e3_l1tp_plan_create": (c_int, [POINTER(c_int32), c_int, POINTER(c_int32), c_int, POINTER(c_void_p)]),
+    "e3_l1tp_plan_destroy": (c_int, [c_void_p]),
+    "e3_l1tp_in1_dim": (c_int, [c_void_p]),
+    "e3_l1tp_out_dim": (c_int, [c_void_p]),
+    "e3_l1tp_weight_shape": (c_int, [c_void_p, c_int, POINTER(c_int), POINTER(c_int)]),
+    "e3_l1tp_norm_len": (c_int, [c_void_p, c_int]),
+    "e3_l1tp_packed_bytes": (c_int64, [c_void_p, c_int]),
+    "e3_l1tp_pack_weights": (c_int, [c_void_p, VoidP4, VoidP4, c_int, c_void_p, c_void_p]),
+    "e3_l1tp_forward": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
+                                c_int64, c_int, c_int, c_void_p]),
+    "e3_l1tp_backward_workspace_bytes": (c_int64, [c_void_p, c_int64, c_int]),
+    "e3_l1tp_backward": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, VoidP4, VoidP4, c_void_p, c_int64,
+                                 c_void_p, c_int64, c_void_p, VoidP4, c_void_p, c_int64, c_int, c_void_p]),
+}
+
+
+def load():
+    """Load (once) and return the ctypes handle.  Raises RuntimeError when the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP library has not been built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C scalable-e3-gnn_amd/csrc`). "
+            "There is no CPU fallback.")
+    import torch  # noqa: F401  (maps PyTorch's libamdhip64 before ours is resolved)
+
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name, None)
+        if fn is None:
+            continue  # entry points that are declared but land later are reported by tests
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str = ""):
+    if status != E3_OK:
+        lib = load()
+        msg = lib.e3_status_string(status).decode()
+        if status == 5:
+            msg += " — " + lib.e3_last_hip_error().decode()
+        raise RuntimeError(f"libe3gnn_hip: {what}: {msg} (status {status})")
+
+
+def blocks_array(blocks):
+    flat = [int(v) for b in blocks for v in b]
+    return (c_int32 * len(flat))(*flat), len(blocks)
+
+
+def ptr4(tensors):
+    """4-entry void* array from a list of 4 optional tensors."""
+    return VoidP4(*[(t.data_ptr() if (t is not None and t.numel() > 0) else None) for t in tensors])
+
+
+def dtype_code(dtype) -> int:
+    import torch
+
+    try:
+        return {torch.float32: E3_F32, torch.float64: E3_F64, torch.bfloat16: E3_BF16}[dtype]
+    except KeyError:
+        raise RuntimeError(f"libe3gnn_hip supports float32 / float64 / bfloat16, got {dtype}") from None
