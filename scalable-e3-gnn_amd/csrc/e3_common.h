@@ -63,6 +63,8 @@ struct PlanDev {
   const int32_t* ocol;  // [sum M] first out column of channel m of class c
 };
 
+struct Mfma;
+
 }  // namespace e3
 
 struct e3_l1tp_plan {
@@ -75,7 +77,7 @@ struct e3_l1tp_plan {
   int wrows[4], wcols[4];
   int normlen[4];
   // MFMA path (filled by mfma_plan_init)
-  struct Mfma* mfma = nullptr;
+  e3::Mfma* mfma = nullptr;
 };
 
 namespace e3 {

@@ -116,17 +116,17 @@ def test_generic_and_mfma_agree_and_edge_shapes():
         a = mod(x, y)
         mod.kernel = 0
         b = mod(x, y)
-        close(b, a.double().cpu().numpy(), 1e-5, f"B={B}")
+        close(b, a.detach().double().cpu().numpy(), 1e-5, f"B={B}")
     # empty batch
     out = mod(torch.zeros(0, 128, device=DEV), torch.zeros(0, 4, device=DEV))
     assert out.shape == (0, 128)
     # in2 broadcast == expanded
     x = torch.randn(100, 128, device=DEV)
     y1 = torch.randn(1, 4, device=DEV)
-    close(mod(x, y1), mod(x, y1.expand(100, 4).contiguous()).double().cpu().numpy(), 1e-6, "broadcast")
+    close(mod(x, y1), mod(x, y1.expand(100, 4).contiguous()).detach().double().cpu().numpy(), 1e-6, "broadcast")
     # row-strided (non-contiguous) inputs
     xx = torch.randn(100, 200, device=DEV)
-    close(mod(xx[:, 5:133], y1), mod(xx[:, 5:133].contiguous(), y1).double().cpu().numpy(), 1e-7, "strided")
+    close(mod(xx[:, 5:133], y1), mod(xx[:, 5:133].contiguous(), y1).detach().double().cpu().numpy(), 1e-7, "strided")
 
 
 def test_linearity_equivariance_parity_at_scale():
