@@ -14,6 +14,7 @@
 #include "e3_common.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace e3 {
 
@@ -27,7 +28,7 @@ struct MRun {  // one run of in1 channels feeding one output class
 };
 
 struct MfmaDev {
-  int D1, Dout, SI, SO;
+  int D1, Dout, SI, SJ;  // SJ: row stride of the per-job out tile (odd)
   int M[4], NT[4], Mpad[4];
   int woff[4];       // float offset of the class's packed weights [Kpad][Mpad]
   int wtotal;        // floats of packed weights
@@ -36,6 +37,7 @@ struct MfmaDev {
   int ocol_off[4];
   int w_in_lds;
   int nwaves;
+  int nbuf;          // in-tile buffers per wave (2 = LDS-DMA prefetch of the next tile)
   const MRun* runs;
   const int32_t* ocol;
 };
@@ -50,6 +52,7 @@ struct Mfma {
   std::vector<PackRun> h_pack;
   MRun* d_runs = nullptr;
   PackRun* d_pack = nullptr;
+  MfmaDev* d_dev = nullptr;
   bool usable = false;
   size_t lds_bytes = 0;
 };
@@ -65,7 +68,7 @@ int mfma_plan_init(e3_l1tp_plan* P) {
   d.D1 = p.D1;
   d.Dout = p.Dout;
   d.SI = p.D1 | 1;
-  d.SO = p.Dout | 1;
+  d.SJ = (p.M[2] + p.M[3] > 0) ? 97 : 33;
   int woff = 0;
   for (int c = 0; c < 4; ++c) {
     d.M[c] = p.M[c];
@@ -97,17 +100,26 @@ int mfma_plan_init(e3_l1tp_plan* P) {
     if (p.M[c] > 0) woff += wrow * d.Mpad[c];
   }
   d.wtotal = woff;
-  // LDS plan: [weights?][ocol table][nwaves x (in tile + out tile)]
-  size_t per_wave = (size_t)32 * (d.SI + d.SO) * 4;
-  size_t tables = (size_t)(p.M[0] + p.M[1] + p.M[2] + p.M[3]) * 4 + 64;
+  // LDS plan: [weights?][ocol table][nwaves x (nbuf in-tiles + job out-tile)]
+  const size_t in_tile = ((size_t)32 * d.SI + 128) * 4, out_tile = (size_t)32 * d.SJ * 4;
+  size_t tables = (size_t)((p.M[0] + p.M[1] + p.M[2] + p.M[3] + 15) & ~15) * 4 + (size_t)((p.Dout + 15) & ~15) * 4;
   size_t wbytes = (size_t)d.wtotal * 4;
-  d.w_in_lds = (wbytes + tables + 4 * per_wave <= (size_t)kLdsBudget) ? 1 : 0;
+  auto waves_for = [&](size_t fixed, int nbuf) -> int {
+    size_t per_wave = in_tile * nbuf + out_tile;
+    if (fixed + per_wave > (size_t)kLdsBudget) return 0;
+    return (int)std::min<size_t>(((size_t)kLdsBudget - fixed) / per_wave, 8);
+  };
+  // preference: weights in LDS, then double buffering with >= 3 waves, else single buffer with more waves
+  d.w_in_lds = waves_for(tables + wbytes, 1) >= 2 ? 1 : 0;
   size_t fixed = tables + (d.w_in_lds ? wbytes : 0);
-  int nw = fixed + per_wave <= (size_t)kLdsBudget ? (int)(((size_t)kLdsBudget - fixed) / per_wave) : 0;
-  nw = std::min(nw, 8);
-  d.nwaves = nw;
-  m->usable = nw >= 1 && d.wtotal > 0;
-  m->lds_bytes = fixed + (size_t)nw * per_wave;
+  int nw2 = waves_for(fixed, 2), nw1 = waves_for(fixed, 1);
+  const char* force = getenv("E3_MFMA_NBUF");  // tuning knob: force single (1) / double (2) buffering
+  bool want2 = force ? (atoi(force) == 2 && nw2 >= 1) : false;  // measured: more waves beats prefetch (profiles/r01)
+  if (want2) { d.nbuf = 2; d.nwaves = nw2; }
+  else { d.nbuf = 1; d.nwaves = nw1; }
+  if (const char* mw = getenv("E3_MFMA_MAXWAVES")) d.nwaves = std::max(1, std::min(d.nwaves, atoi(mw)));
+  m->usable = d.nwaves >= 1 && d.wtotal > 0;
+  m->lds_bytes = fixed + (size_t)d.nwaves * (in_tile * d.nbuf + out_tile);
   return E3_OK;
 }
 
@@ -123,6 +135,8 @@ int mfma_plan_upload(e3_l1tp_plan* P) {
     E3_HIP_CHECK(hipMemcpy(m->d_pack, m->h_pack.data(), m->h_pack.size() * sizeof(PackRun), hipMemcpyHostToDevice));
   m->dev.runs = m->d_runs;
   m->dev.ocol = P->dev.ocol;
+  E3_HIP_CHECK(hipMalloc((void**)&m->d_dev, sizeof(MfmaDev)));
+  E3_HIP_CHECK(hipMemcpy(m->d_dev, &m->dev, sizeof(MfmaDev), hipMemcpyHostToDevice));
   return mfma_set_lds_attr();
 }
 
@@ -130,6 +144,7 @@ void mfma_plan_free(e3_l1tp_plan* P) {
   if (!P->mfma) return;
   if (P->mfma->d_runs) (void)hipFree(P->mfma->d_runs);
   if (P->mfma->d_pack) (void)hipFree(P->mfma->d_pack);
+  if (P->mfma->d_dev) (void)hipFree(P->mfma->d_dev);
   delete P->mfma;
   P->mfma = nullptr;
 }
@@ -194,15 +209,99 @@ int mfma_pack(const e3_l1tp_plan* P, const void* const w[4], const void* const n
 // -------------------------------------------------------------------------------------------------
 // forward kernel
 // -------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_void_t;
+
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ void wave_sync_lds() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+struct YRow { float y0, yx, yy, yz; };
+
+// One run of input channels contracted on the matrix core.  KIND selects how the B operand is built:
+//   0: x*y0 (or x when y0 == 1 is passed)   -> acc A0
+//   1: <v, Y1>                              -> acc A0
+//   2: v_c * y0   (c = x,y,z)               -> acc A0,A1,A2
+//   3: (v x Y1)_c                           -> acc A0,A1,A2
+// `xp` points at this lane's row + run column (+ cstride*half), `wp` at W'[wrow+half][32t+j].
+// Steps are issued in groups of U with the next group's LDS reads in flight behind the MFMAs.
+template <int KIND, int U>
+__device__ __forceinline__ void run_gemm(const float* __restrict__ xp, const float* __restrict__ wp, const int Mpad,
+                                         const int count, const int half, const YRow y, f32x16& A0, f32x16& A1,
+                                         f32x16& A2) {
+  constexpr int NB = (KIND == 0) ? 1 : 3;
+  constexpr int CS = (KIND == 0) ? 1 : 3;
+  const int npair = count >> 1;
+  const int ngrp = npair / U;
+  auto load = [&](int p, float& a, float (&x)[NB]) {
+    a = wp[(2 * p) * Mpad];
+#pragma unroll
+    for (int c = 0; c < NB; ++c) x[c] = xp[CS * 2 * p + c];
+  };
+  auto step = [&](float a, const float (&x)[NB], bool valid) {
+    if (KIND == 0) {
+      float b = x[0] * y.y0;
+      A0 = mfma32(a, valid ? b : 0.0f, A0);
+    } else if (KIND == 1) {
+      float b = x[0] * y.yx + x[1] * y.yy + x[2] * y.yz;
+      A0 = mfma32(a, valid ? b : 0.0f, A0);
+    } else if (KIND == 2) {
+      A0 = mfma32(a, valid ? x[0] * y.y0 : 0.0f, A0);
+      A1 = mfma32(a, valid ? x[1] * y.y0 : 0.0f, A1);
+      A2 = mfma32(a, valid ? x[2] * y.y0 : 0.0f, A2);
+    } else {
+      float bx = x[1] * y.yz - x[2] * y.yy;
+      float by = x[2] * y.yx - x[0] * y.yz;
+      float bz = x[0] * y.yy - x[1] * y.yx;
+      A0 = mfma32(a, valid ? bx : 0.0f, A0);
+      A1 = mfma32(a, valid ? by : 0.0f, A1);
+      A2 = mfma32(a, valid ? bz : 0.0f, A2);
+    }
+  };
+  if (ngrp > 0) {
+    float a[U], x[U][NB];
+#pragma unroll
+    for (int u = 0; u < U; ++u) load(u, a[u], x[u]);
+    for (int g = 1; g < ngrp; ++g) {
+      float an[U], xn[U][NB];
+#pragma unroll
+      for (int u = 0; u < U; ++u) load(g * U + u, an[u], xn[u]);
+#pragma unroll
+      for (int u = 0; u < U; ++u) step(a[u], x[u], true);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        a[u] = an[u];
+#pragma unroll
+        for (int c = 0; c < NB; ++c) x[u][c] = xn[u][c];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) step(a[u], x[u], true);
+  }
+  for (int p = ngrp * U; p < npair; ++p) {
+    float a, x[NB];
+    load(p, a, x);
+    step(a, x, true);
+  }
+  if (count & 1) {  // odd tail: the second k of the pair is a zero weight row; its B lane must be a clean 0
+    float a, x[NB];
+    load(npair, a, x);
+    step(a, x, half == 0);
+  }
 }
 
 template <bool W_IN_LDS>
 __global__ __launch_bounds__(512) void l1tp_fwd_mfma_kernel(const float* __restrict__ in1, int64_t ld1,
                                                             const float* __restrict__ in2, int64_t ld2,
                                                             const float* __restrict__ packed, float* __restrict__ out,
-                                                            int64_t ldo, int64_t B, MfmaDev d) {
+                                                            int64_t ldo, int64_t B, const MfmaDev* __restrict__ dp,
+                                                            const MRun* __restrict__ runs,
+                                                            const int32_t* __restrict__ ocol_tab) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   float* lds = reinterpret_cast<float*>(smem_raw);
   const int tid = threadIdx.x;
@@ -210,158 +309,176 @@ __global__ __launch_bounds__(512) void l1tp_fwd_mfma_kernel(const float* __restr
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31;     // row of the tile owned by this lane
   const int half = lane >> 5;  // k parity supplied by this lane
-  const int Mtot = d.M[0] + d.M[1] + d.M[2] + d.M[3];
+  const int D1 = dp->D1, Dout = dp->Dout, SI = dp->SI, SJ = dp->SJ, wtotal = dp->wtotal, nwaves = dp->nwaves,
+            nbuf = dp->nbuf;
+  // per-class constants, hoisted once (kept in SGPRs / lanes of a spill VGPR, not re-fetched per job)
+  int cM[4], cMpad[4], cNT[4], cWoff[4], cOoff[4], cNrun[4][3], cRoff[4][3];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    cM[c] = dp->M[c]; cMpad[c] = dp->Mpad[c]; cNT[c] = dp->NT[c]; cWoff[c] = dp->woff[c]; cOoff[c] = dp->ocol_off[c];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) { cNrun[c][s] = dp->nrun[c][s]; cRoff[c][s] = dp->roff[c][s]; }
+  }
+  const int Mtot = cM[0] + cM[1] + cM[2] + cM[3];
 
-  // ---- LDS carve-up: [W'][ocol][per wave: in tile, out tile] ----
+  // ---- LDS carve-up: [W'][normcol][ocol][per wave: nbuf x (in-tile + Y tile), one job out-tile] ----
   float* wl = lds;
-  int* ocl = reinterpret_cast<int*>(lds + (W_IN_LDS ? d.wtotal : 0));
+  float* nrm = lds + (W_IN_LDS ? wtotal : 0);
+  int* ocl = reinterpret_cast<int*>(nrm + ((Dout + 15) & ~15));
   float* tiles = reinterpret_cast<float*>(ocl + ((Mtot + 15) & ~15));
-  float* xt = tiles + (size_t)wave * 32 * (d.SI + d.SO);
-  float* ot = xt + 32 * d.SI;
+  const int in_sz = 32 * SI + 128;  // in-tile + [32][4] Y tile
+  float* xbuf = tiles + (size_t)wave * (in_sz * nbuf + 32 * SJ);
+  float* ot = xbuf + in_sz * nbuf;
   if (W_IN_LDS)
-    for (int i = tid; i < d.wtotal; i += blockDim.x) wl[i] = packed[i];
-  for (int i = tid; i < Mtot; i += blockDim.x) ocl[i] = d.ocol[i];
+    for (int i = tid; i < wtotal; i += blockDim.x) wl[i] = packed[i];
+  for (int i = tid; i < Dout; i += blockDim.x) nrm[i] = packed[wtotal + i];
+  for (int i = tid; i < Mtot; i += blockDim.x) ocl[i] = ocol_tab[i];
   __syncthreads();
   const float* wsrc = W_IN_LDS ? wl : packed;
-  const float* normcol = packed + d.wtotal;
 
   const int64_t ntiles = (B + 31) / 32;
-  for (int64_t tile = (int64_t)blockIdx.x * d.nwaves + wave; tile < ntiles; tile += (int64_t)gridDim.x * d.nwaves) {
+  const int64_t tstride = (int64_t)gridDim.x * nwaves;
+
+  // Async stage of one 32-row tile by LDS-DMA (no VGPR round trip, nothing for the compiler to wait on):
+  // in1 rows as 256-B segments, then the [32][4] Y tile (two pieces of 16 rows, per-lane source).
+  auto stage = [&](int64_t tile, float* dst) {
     const int64_t row0 = tile * 32;
     const int nrows = (int)((B - row0) < 32 ? (B - row0) : 32);
-    // ---- stage in1 tile (coalesced 256-B row segments) ----
-    for (int dc = lane; dc < d.D1; dc += 64) {
-      float v[32];
-#pragma unroll
-      for (int r = 0; r < 32; ++r) v[r] = (r < nrows) ? in1[(row0 + r) * ld1 + dc] : 0.0f;
-#pragma unroll
-      for (int r = 0; r < 32; ++r) xt[r * d.SI + dc] = v[r];
+    const int full = D1 & ~63;
+    const float* srow = in1 + row0 * ld1 + lane;
+    float* drow = dst;
+    for (int r = 0; r < 32; ++r) {
+      if (r < nrows) {
+        for (int dc = 0; dc < full; dc += 64)
+          __builtin_amdgcn_global_load_lds((glb_void_t*)(srow + dc), (lds_void_t*)(drow + dc), 4, 0, 0);
+        if (full + lane < D1)
+          __builtin_amdgcn_global_load_lds((glb_void_t*)(srow + full), (lds_void_t*)(drow + full), 4, 0, 0);
+      } else {
+        for (int dc = lane; dc < D1; dc += 64) drow[dc] = 0.0f;
+      }
+      srow += ld1;
+      drow += SI;
     }
-    float y0 = 0.f, y1x = 0.f, y1y = 0.f, y1z = 0.f;
-    if (j < nrows) {
-      const float* yp = in2 + (row0 + j) * ld2;
-      y0 = yp[0]; y1x = yp[1]; y1y = yp[2]; y1z = yp[3];
+    float* ydst = dst + 32 * SI;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int yr = h * 16 + (lane >> 2);
+      if (yr < nrows)
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(in2 + (row0 + yr) * ld2 + (lane & 3)),
+                                         (lds_void_t*)(ydst + h * 64), 4, 0, 0);
+      else
+        ydst[h * 64 + lane] = 0.0f;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    const float* xr = xt + j * d.SI;  // this lane's row
+  };
+
+  int64_t tile = (int64_t)blockIdx.x * nwaves + wave;
+  int cur = 0;
+  if (tile < ntiles) stage(tile, xbuf);
+  for (; tile < ntiles; tile += tstride) {
+    const int64_t row0 = tile * 32;
+    const int nrows = (int)((B - row0) < 32 ? (B - row0) : 32);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wave_sync_lds();
+    const float* xt = xbuf + cur * in_sz;
+    if (nbuf == 2 && tile + tstride < ntiles) stage(tile + tstride, xbuf + (cur ^ 1) * in_sz);
+    const float* yp = xt + 32 * SI + 4 * j;
+    const YRow y = {yp[0], yp[1], yp[2], yp[3]};
+    const YRow yone = {1.0f, y.yx, y.yy, y.yz};
+    const float* xr = xt + j * SI;  // this lane's row
+    float* const obase = out + row0 * ldo;
+    const uint32_t ldo32 = (uint32_t)ldo;
 
     // ---- scalar output classes (0e, 0o) ----
-    for (int cls = 0; cls < 2; ++cls) {
-      if (d.M[cls] == 0) continue;
-      const int Mpad = d.Mpad[cls];
-      for (int t = 0; t < d.NT[cls]; ++t) {
-        f32x16 acc = {0};
-        const float* wbase = wsrc + d.woff[cls] + t * 32 + j;
-        for (int ri = 0; ri < d.nrun[cls][0]; ++ri) {
-          const MRun run = d.runs[d.roff[cls][0] + ri];
-          const float* wp = wbase + (size_t)(run.wrow + half) * Mpad;
-#pragma unroll 4
-          for (int k0 = 0; k0 < run.count; k0 += 2) {
-            const int kk = k0 + half;
-            float b = (kk < run.count) ? xr[run.col + kk] * y0 : 0.0f;
-            float a = wp[(size_t)k0 * Mpad];
-            acc = mfma32(a, b, acc);
-          }
-        }
-        for (int ri = 0; ri < d.nrun[cls][1]; ++ri) {
-          const MRun run = d.runs[d.roff[cls][1] + ri];
-          const float* wp = wbase + (size_t)(run.wrow + half) * Mpad;
-#pragma unroll 4
-          for (int k0 = 0; k0 < run.count; k0 += 2) {
-            const int kk = k0 + half;
-            float b = 0.0f;
-            if (kk < run.count) {
-              const float* v = xr + run.col + 3 * kk;
-              b = v[0] * y1x + v[1] * y1y + v[2] * y1z;
-            }
-            float a = wp[(size_t)k0 * Mpad];
-            acc = mfma32(a, b, acc);
-          }
-        }
-        const int* oc = ocl + d.ocol_off[cls];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          int ch = t * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
-          if (ch < d.M[cls]) ot[j * d.SO + oc[ch]] = acc[r];
+    for (int cls = 0; cls < 2; ++cls) {
+      const int M = cM[cls];
+      if (M == 0) continue;
+      const int Mpad = cMpad[cls];
+      const int* oc = ocl + cOoff[cls];
+      for (int t = 0; t < cNT[cls]; ++t) {
+        f32x16 acc = {0}, d1 = {0}, d2 = {0};
+        const float* wbase = wsrc + cWoff[cls] + t * 32 + j + half * Mpad;
+        for (int ri = 0; ri < cNrun[cls][0]; ++ri) {
+          const MRun run = runs[cRoff[cls][0] + ri];
+          run_gemm<0, 4>(xr + run.col + half, wbase + run.wrow * Mpad, Mpad, run.count, half, y, acc, d1, d2);
         }
+        for (int ri = 0; ri < cNrun[cls][1]; ++ri) {
+          const MRun run = runs[cRoff[cls][1] + ri];
+          run_gemm<1, 4>(xr + run.col + 3 * half, wbase + run.wrow * Mpad, Mpad, run.count, half, y, acc, d1, d2);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[j * SJ + 8 * (r >> 2) + 4 * half + (r & 3)] = acc[r];
+        wave_sync_lds();
+        {  // copy out: two rows per store instruction (128-B segments)
+          const int lc = lane & 31, rs = lane >> 5;
+          const int ch = t * 32 + lc;
+          if (ch < M) {
+            const int col = oc[ch];
+            const float nm = nrm[col];
+            uint32_t off = (uint32_t)col + rs * ldo32;
+            const float* src = ot + rs * SJ + lc;
+#pragma unroll 4
+            for (int r = rs; r < nrows; r += 2) {
+              obase[off] = *src * nm;
+              off += 2 * ldo32;
+              src += 2 * SJ;
+            }
+          }
+        }
+        wave_sync_lds();
       }
     }
     // ---- vector output classes (1e, 1o) ----
+#pragma unroll
     for (int cls = 2; cls < 4; ++cls) {
-      if (d.M[cls] == 0) continue;
-      const int Mpad = d.Mpad[cls];
-      for (int t = 0; t < d.NT[cls]; ++t) {
-        const float* wbase = wsrc + d.woff[cls] + t * 32 + j;
-        f32x16 t0 = {0};
-        for (int ri = 0; ri < d.nrun[cls][0]; ++ri) {
-          const MRun run = d.runs[d.roff[cls][0] + ri];
-          const float* wp = wbase + (size_t)(run.wrow + half) * Mpad;
-#pragma unroll 4
-          for (int k0 = 0; k0 < run.count; k0 += 2) {
-            const int kk = k0 + half;
-            float b = (kk < run.count) ? xr[run.col + kk] : 0.0f;
-            t0 = mfma32(wp[(size_t)k0 * Mpad], b, t0);
-          }
+      const int M = cM[cls];
+      if (M == 0) continue;
+      const int Mpad = cMpad[cls];
+      const int* oc = ocl + cOoff[cls];
+      for (int t = 0; t < cNT[cls]; ++t) {
+        const float* wbase = wsrc + cWoff[cls] + t * 32 + j + half * Mpad;
+        f32x16 t0 = {0}, d1 = {0}, d2 = {0};
+        for (int ri = 0; ri < cNrun[cls][0]; ++ri) {
+          const MRun run = runs[cRoff[cls][0] + ri];
+          run_gemm<0, 4>(xr + run.col + half, wbase + run.wrow * Mpad, Mpad, run.count, half, yone, t0, d1, d2);
         }
-        f32x16 fx = t0 * y1x, fy = t0 * y1y, fz = t0 * y1z;
-        for (int ri = 0; ri < d.nrun[cls][1]; ++ri) {
-          const MRun run = d.runs[d.roff[cls][1] + ri];
-          const float* wp = wbase + (size_t)(run.wrow + half) * Mpad;
-#pragma unroll 2
-          for (int k0 = 0; k0 < run.count; k0 += 2) {
-            const int kk = k0 + half;
-            float bx = 0.f, by = 0.f, bz = 0.f;
-            if (kk < run.count) {
-              const float* v = xr + run.col + 3 * kk;
-              bx = v[0] * y0; by = v[1] * y0; bz = v[2] * y0;
-            }
-            float a = wp[(size_t)k0 * Mpad];
-            fx = mfma32(a, bx, fx);
-            fy = mfma32(a, by, fy);
-            fz = mfma32(a, bz, fz);
-          }
+        f32x16 fx = t0 * y.yx, fy = t0 * y.yy, fz = t0 * y.yz;
+        for (int ri = 0; ri < cNrun[cls][1]; ++ri) {
+          const MRun run = runs[cRoff[cls][1] + ri];
+          run_gemm<2, 2>(xr + run.col + 3 * half, wbase + run.wrow * Mpad, Mpad, run.count, half, y, fx, fy, fz);
         }
-        for (int ri = 0; ri < d.nrun[cls][2]; ++ri) {
-          const MRun run = d.runs[d.roff[cls][2] + ri];
-          const float* wp = wbase + (size_t)(run.wrow + half) * Mpad;
-#pragma unroll 2
-          for (int k0 = 0; k0 < run.count; k0 += 2) {
-            const int kk = k0 + half;
-            float bx = 0.f, by = 0.f, bz = 0.f;
-            if (kk < run.count) {
-              const float* v = xr + run.col + 3 * kk;
-              bx = v[1] * y1z - v[2] * y1y;  // (v x Y1)
-              by = v[2] * y1x - v[0] * y1z;
-              bz = v[0] * y1y - v[1] * y1x;
-            }
-            float a = wp[(size_t)k0 * Mpad];
-            fx = mfma32(a, bx, fx);
-            fy = mfma32(a, by, fy);
-            fz = mfma32(a, bz, fz);
-          }
+        for (int ri = 0; ri < cNrun[cls][2]; ++ri) {
+          const MRun run = runs[cRoff[cls][2] + ri];
+          run_gemm<3, 2>(xr + run.col + 3 * half, wbase + run.wrow * Mpad, Mpad, run.count, half, y, fx, fy, fz);
         }
-        const int* oc = ocl + d.ocol_off[cls];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          int ch = t * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
-          if (ch < d.M[cls]) {
-            float* o = ot + j * d.SO + oc[ch];
-            o[0] = fx[r]; o[1] = fy[r]; o[2] = fz[r];
+          float* o = ot + j * SJ + 3 * (8 * (r >> 2) + 4 * half + (r & 3));
+          o[0] = fx[r]; o[1] = fy[r]; o[2] = fz[r];
+        }
+        wave_sync_lds();
+        const int width = (M - t * 32 < 32 ? M - t * 32 : 32) * 3;
+        for (int lc = lane; lc < width; lc += 64) {
+          const int chl = lc / 3, comp = lc - 3 * chl;
+          const int col = oc[t * 32 + chl] + comp;
+          const float nm = nrm[col];
+          uint32_t off = (uint32_t)col;
+          const float* src = ot + lc;
+#pragma unroll 8
+          for (int r = 0; r < nrows; ++r) {
+            obase[off] = *src * nm;
+            off += ldo32;
+            src += SJ;
           }
         }
+        wave_sync_lds();
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // ---- copy out (coalesced), norm applied per output column ----
-    for (int oc = lane; oc < d.Dout; oc += 64) {
-      const float nm = normcol[oc];
-#pragma unroll 8
-      for (int r = 0; r < nrows; ++r) out[(row0 + r) * ldo + oc] = ot[r * d.SO + oc] * nm;
+    if (nbuf == 1) {
+      if (tile + tstride < ntiles) stage(tile + tstride, xbuf);
+    } else {
+      cur ^= 1;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -382,10 +499,12 @@ int mfma_forward(const e3_l1tp_plan* P, const void* in1, int64_t ld1, const void
   int grid = (int)std::min<int64_t>((ntiles + d.nwaves - 1) / d.nwaves, 256);
   if (d.w_in_lds)
     hipLaunchKernelGGL(l1tp_fwd_mfma_kernel<true>, dim3(grid), dim3(64 * d.nwaves), m->lds_bytes, stream,
-                       (const float*)in1, ld1, (const float*)in2, ld2, (const float*)packed, (float*)out, ldo, B, d);
+                       (const float*)in1, ld1, (const float*)in2, ld2, (const float*)packed, (float*)out, ldo, B,
+                       m->d_dev, m->d_runs, P->dev.ocol);
   else
     hipLaunchKernelGGL(l1tp_fwd_mfma_kernel<false>, dim3(grid), dim3(64 * d.nwaves), m->lds_bytes, stream,
-                       (const float*)in1, ld1, (const float*)in2, ld2, (const float*)packed, (float*)out, ldo, B, d);
+                       (const float*)in1, ld1, (const float*)in2, ld2, (const float*)packed, (float*)out, ldo, B,
+                       m->d_dev, m->d_runs, P->dev.ocol);
   E3_HIP_CHECK(hipGetLastError());
   return E3_OK;
 }
