@@ -119,6 +119,42 @@ int e3_l1tp_backward(const e3_l1tp_plan* plan,
                      void* workspace,
                      int64_t B, int dtype, void* stream);
 
+/* =================================================================================================
+ * Radius graph (builder-defined: the reference mount has no graph code; the spec
+ * below is this repo's contract and oracle/radius_graph_oracle.c is its CPU statement).
+ *
+ *   grid   : per axis a,  n_a = clamp(floor((hi_a-lo_a) / (r*1.0001f)), 1, 256)   (fp32 arithmetic)
+ *            cell c_a(p) = clamp((int)floorf((p_a-lo_a) * (n_a/(hi_a-lo_a))), 0, n_a-1)
+ *   key    : 30-bit Morton interleave of (cx,cy,cz) (x lowest bit)
+ *   order  : stable sort by key; new id = rank; perm[new] = old
+ *   edge   : (src=j -> dst=i), i != j, iff d2 <= fl32(r*r) with
+ *            d2 = fl32(fl32(fl32(dx*dx)+fl32(dy*dy))+fl32(dz*dz)), dx = fl32(x_i-x_j) (no FMA contraction)
+ *   output : CSR by dst in NEW ids: rowptr[N+1] (int32), src[E] (int32) ascending inside each row.
+ * All integer outputs are bit-exact functions of the inputs.
+ *
+ * Call sequence (sizes are only known after the count pass, so the caller allocates `src`):
+ *   e3_rg_workspace_bytes -> e3_rg_sort_count (fills perm, sorted_pos4, rowptr) -> read E = rowptr[N]
+ *   -> e3_rg_fill (fills src).
+ * ================================================================================================= */
+typedef struct e3_rg_params {
+  float lo[3], hi[3];
+  float r;
+  int32_t n[3];   /* filled by e3_rg_grid */
+  float inv[3];   /* filled by e3_rg_grid */
+  int32_t bits;   /* filled by e3_rg_grid: Morton bits per axis */
+} e3_rg_params;
+
+int     e3_rg_grid(e3_rg_params* prm);                     /* host only: derives n, inv, bits from lo/hi/r */
+int64_t e3_rg_workspace_bytes(int64_t N, const e3_rg_params* prm);
+/* pos [N,3] fp32 contiguous (device). Outputs (device): perm [N] int32, sorted_pos4 [N,4] fp32
+ * (x,y,z,0 in new order), rowptr [N+1] int32. */
+int e3_rg_sort_count(const float* pos, int64_t N, const e3_rg_params* prm,
+                     int32_t* perm, float* sorted_pos4, int32_t* rowptr,
+                     void* workspace, int64_t workspace_bytes, void* stream);
+/* src [E] int32 (device), E = rowptr[N]; must follow e3_rg_sort_count with the same workspace. */
+int e3_rg_fill(int64_t N, const e3_rg_params* prm, const float* sorted_pos4, const int32_t* rowptr,
+               int32_t* src, void* workspace, int64_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -38,6 +38,11 @@ SIGNATURES = {
     "e3_l1tp_forward": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
                                 c_int64, c_int, c_int, c_void_p]),
     "e3_l1tp_backward_workspace_bytes": (c_int64, [c_void_p, c_int64, c_int]),
+    "e3_rg_grid": (c_int, [c_void_p]),
+    "e3_rg_workspace_bytes": (c_int64, [c_int64, c_void_p]),
+    "e3_rg_sort_count": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                 c_void_p]),
+    "e3_rg_fill": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "e3_l1tp_backward": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, VoidP4, VoidP4, c_void_p, c_int64,
                                  c_void_p, c_int64, c_void_p, VoidP4, c_void_p, c_int64, c_int, c_void_p]),
 }
