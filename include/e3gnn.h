@@ -155,6 +155,25 @@ int e3_rg_sort_count(const float* pos, int64_t N, const e3_rg_params* prm,
 int e3_rg_fill(int64_t N, const e3_rg_params* prm, const float* sorted_pos4, const int32_t* rowptr,
                int32_t* src, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* =================================================================================================
+ * Edge / node stages of the SEGNN forward around the tensor product (builder-defined, SURVEY.md
+ * §8a-N2, N3; fp32).  Graph = CSR by dst from e3_rg_* (rowptr [N+1], src [E], positions pos4 [N,4]).
+ *   rel_e  = x[src_e] - x[dst_e];  d_e = |rel_e|
+ *   Y_e    = [1, sqrt(3) rel_e/d_e]   ("component" normalised real SH, l<=1, xyz order; Y1 = 0 if d_e = 0)
+ *   A_i    = [1, mean_{e -> i} Y1_e]  (node attribute; [1,0,0,0] for isolated nodes)
+ * ================================================================================================= */
+/* edge_y [E,4], edge_d [E] (may be NULL), node_a [N,4] (may be NULL) */
+int e3_edge_geometry(const float* pos4, const int32_t* rowptr, const int32_t* src, int64_t N,
+                     float* edge_y, float* edge_d, float* node_a, void* stream);
+/* out[e] = [ h[dst_e] (D) | h[src_e] (D) | extra[e] (n_extra, may be 0) ]   row strides in elements */
+int e3_gather_concat(const float* h, int64_t ld_h, int D, const int32_t* rowptr, const int32_t* src, int64_t N,
+                     const float* extra, int n_extra, float* out, int64_t ld_out, void* stream);
+/* gate: in = [ns scalars | nv gate scalars | nv vectors (xyz adjacent)] -> out = [silu(s) | sigmoid(g)*v] */
+int e3_gate(const float* in, int64_t ld_in, float* out, int64_t ld_out, int64_t B, int ns, int nv, void* stream);
+/* agg[i] = sum over row i of msg[e] (fixed edge order => bitwise reproducible); D columns */
+int e3_segment_sum(const float* msg, int64_t ld_msg, const int32_t* rowptr, int64_t N, int D,
+                   float* agg, int64_t ld_agg, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -43,6 +43,11 @@ SIGNATURES = {
     "e3_rg_sort_count": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                  c_void_p]),
     "e3_rg_fill": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "e3_edge_geometry": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "e3_gather_concat": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p,
+                                 c_int64, c_void_p]),
+    "e3_gate": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p]),
+    "e3_segment_sum": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p]),
     "e3_l1tp_backward": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, VoidP4, VoidP4, c_void_p, c_int64,
                                  c_void_p, c_int64, c_void_p, VoidP4, c_void_p, c_int64, c_int, c_void_p]),
 }

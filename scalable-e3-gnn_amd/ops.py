@@ -1,0 +1,83 @@
+"""Edge / node stages of the SEGNN forward (host side of ``e3_edge_geometry``, ``e3_gather_concat``,
+``e3_gate``, ``e3_segment_sum`` in include/e3gnn.h).  Builder-defined, fp32,
+forward only.  ROCm tensors only; no CPU path."""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from .radius_graph import RadiusGraph
+
+
+def _check(t: torch.Tensor, name: str):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: ROCm tensor required (no CPU path)")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name}: float32 required, got {t.dtype}")
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def edge_geometry(g: RadiusGraph, want_dist=True, want_node_attr=True):
+    """-> Y [E,4], d [E] | None, A [N,4] | None"""
+    _check(g.pos4, "pos4")
+    N, E, dev = g.rowptr.numel() - 1, g.num_edges, g.pos4.device
+    Y = torch.empty((E, 4), dtype=torch.float32, device=dev)
+    d = torch.empty(E, dtype=torch.float32, device=dev) if want_dist else None
+    A = torch.empty((N, 4), dtype=torch.float32, device=dev) if want_node_attr else None
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().e3_edge_geometry(g.pos4.data_ptr(), g.rowptr.data_ptr(), g.src.data_ptr(), N,
+                                                Y.data_ptr(), d.data_ptr() if d is not None else None,
+                                                A.data_ptr() if A is not None else None, _stream(Y)),
+                   "e3_edge_geometry")
+    return Y, d, A
+
+
+def gather_concat(h: torch.Tensor, g: RadiusGraph, extra: torch.Tensor | None = None) -> torch.Tensor:
+    """[E, 2D+n_extra] = [h[dst] | h[src] | extra]"""
+    _check(h, "h")
+    if h.stride(-1) != 1:
+        h = h.contiguous()
+    N, D = h.shape
+    E = g.num_edges
+    nx = 0
+    if extra is not None:
+        _check(extra, "extra")
+        extra = extra.reshape(E, -1).contiguous()
+        nx = extra.shape[1]
+    out = torch.empty((E, 2 * D + nx), dtype=torch.float32, device=h.device)
+    with torch.cuda.device(h.device):
+        _lib.check(_lib.load().e3_gather_concat(h.data_ptr(), h.stride(0), D, g.rowptr.data_ptr(), g.src.data_ptr(), N,
+                                                extra.data_ptr() if nx else None, nx, out.data_ptr(), out.stride(0),
+                                                _stream(h)), "e3_gather_concat")
+    return out
+
+
+def gate(x: torch.Tensor, ns: int, nv: int) -> torch.Tensor:
+    """[B, ns + nv + 3nv] (scalars | gates | vectors) -> [B, ns + 3nv] = [silu(s) | sigmoid(g) v]"""
+    _check(x, "x")
+    if x.stride(-1) != 1:
+        x = x.contiguous()
+    B = x.shape[0]
+    assert x.shape[1] == ns + 4 * nv, (x.shape, ns, nv)
+    out = torch.empty((B, ns + 3 * nv), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().e3_gate(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), B, ns, nv,
+                                       _stream(x)), "e3_gate")
+    return out
+
+
+def segment_sum(msg: torch.Tensor, g: RadiusGraph) -> torch.Tensor:
+    """agg[i] = sum of msg rows of CSR row i (fixed order, reproducible)"""
+    _check(msg, "msg")
+    if msg.stride(-1) != 1:
+        msg = msg.contiguous()
+    N = g.rowptr.numel() - 1
+    D = msg.shape[1]
+    agg = torch.empty((N, D), dtype=torch.float32, device=msg.device)
+    with torch.cuda.device(msg.device):
+        _lib.check(_lib.load().e3_segment_sum(msg.data_ptr(), msg.stride(0), g.rowptr.data_ptr(), N, D,
+                                              agg.data_ptr(), agg.stride(0), _stream(msg)), "e3_segment_sum")
+    return agg
