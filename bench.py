@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""bench.py — radius-graph build + SEGNN forward on N MI355X (one process per GPU).
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one synthetic batch already resident in HBM:
+    Morton sort + cell scan (CSR radius graph)  ->  edge geometry  ->  SEGNN forward (L layers)
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline     : the dominant kernel (largest total time among the tensor-product launches), timed live
+                 with HIP events on the launch stream; achieved = algorithmic bytes / avg launch time
+  cpu_baseline : the CPU oracle pipeline (reference op pattern for every TP) on a bounded sample,
+                 all host cores, rank 0, N=1 only.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+import numpy as np
+import torch
+
+METRIC = "particles/sec (octree build + SEGNN fwd), 1M pts l_max=2, 1/2/4/8 MI355X"
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def cutoff(n, k=24.0):
+    return float((3.0 * k / (4.0 * math.pi * n)) ** (1.0 / 3.0))
+
+
+def cpu_baseline(args, state):
+    """Oracle pipeline on `--cpu-sample` particles at the same neighbour density."""
+    from oracle import graph_oracle as G
+    from oracle import segnn_oracle as S
+
+    n = args.cpu_sample
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))  # the GPU box's CPU share for one GPU is 16 cores
+    torch.set_num_threads(cores)
+    g = torch.Generator().manual_seed(0)
+    pos = torch.rand(n, 3, generator=g).numpy()
+    x = torch.randn(n, 4, generator=torch.Generator().manual_seed(1)).numpy()
+    r = cutoff(n)
+    params = {k: v.detach().float().cpu().numpy() for k, v in state.items()}
+    best = None
+    for _ in range(1):
+        t0 = time.perf_counter()
+        perm, rowptr, src = G.graph(pos, [0, 0, 0], [1, 1, 1], r)
+        with torch.no_grad():
+            S.forward_torch_cpu(params, args.hidden, args.layers, "1x0e+1x1o", "1x1o", x[perm], pos[perm], rowptr, src)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return {"value": n / best, "unit": "particles/s", "cores": cores, "kind": "port",
+            "sample": f"{n} particles, same density (k~24, E={len(src)}), lmax={args.lmax} {args.layers} layers H={args.hidden} fp32; "
+                      f"C cell-list graph (1 thread) + torch-CPU SEGNN with the reference's L1TP op pattern ({cores} threads); one timed pass",
+            "seconds": best}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--particles", type=int, default=1_000_000, help="particles per GPU (weak scaling)")
+    ap.add_argument("--hidden", type=int, default=32)
+    ap.add_argument("--layers", type=int, default=4)
+    ap.add_argument("--lmax", type=int, default=1)
+    ap.add_argument("--cpu-sample", type=int, default=20000)
+    ap.add_argument("--timing-json", type=str, default=None, help="also dump per-TP timings here")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import models  # noqa: F401
+    from scalable_e3_gnn_amd import ops, profiling
+    from scalable_e3_gnn_amd.radius_graph import radius_graph
+    from scalable_e3_gnn_amd.segnn import SEGNN
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    if args.lmax != 1:
+        raise SystemExit("only l_max=1 is built so far (l_max=2 is the next §8(f) row)")
+
+    n = args.particles
+    # Replicas-with-sharded-cloud: the global cloud has world*n particles in [0,world)x[0,1)^2; rank k owns the
+    # slab x in [k,k+1).  (Halo exchange across slabs lands with the sharded model)
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    pos = torch.rand(n, 3, device=dev, generator=gen)
+    x = torch.randn(n, 4, device=dev, generator=gen)
+    r = cutoff(n)
+    torch.manual_seed(0)
+    model = SEGNN("1x0e+1x1o", args.hidden, "1x1o", args.layers).to(dev)
+    lo, hi = [0.0, 0.0, 0.0], [1.0, 1.0, 1.0]
+
+    def step():
+        g = radius_graph(pos, r, lo, hi)
+        xs = x[g.perm.long()]
+        with torch.no_grad():
+            out = model(xs, g)
+        return g, out
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    profiling.enable()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        g, out = step()
+    fence()
+    dt = time.perf_counter() - t0
+    prof = profiling.summary()
+    profiling.disable()
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert torch.isfinite(out).all()
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        total_particles = n * world
+        dom_tag, dom = max(prof.items(), key=lambda kv: kv[1]["total_ms"])
+        achieved = dom["bytes_per_launch"] / (dom["avg_ms"] * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(REPO, "profiles", "r01_traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("dominant_kernel_hbm_bytes_per_launch")
+        line = {
+            "metric": METRIC, "value": total_particles / (dt / args.steps), "unit": "particles/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{n} particles/GPU uniform in unit box, radius graph k~24 (E={g.num_edges}), "
+                                   f"SEGNN l_max={args.lmax} {args.layers} layers H={args.hidden} fp32 "
+                                   f"(BASELINE names l_max=2: not built yet, this line is the l_max=1 pipeline)",
+                       "particles_per_gpu": n, "edges_per_gpu": g.num_edges, "hidden": args.hidden,
+                       "layers": args.layers, "lmax": args.lmax,
+                       "parallelism": "1 process/GPU, independent spatial shards (no halo yet)" if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "kernel": "e3::l1tp_fwd_mfma_kernel  [" + dom_tag + "]",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "avg_launch_ms": dom["avg_ms"], "launches": dom["launches"],
+                         "algorithmic_bytes_per_launch": dom["bytes_per_launch"],
+                         "l1tp_share_of_step": sum(v["total_ms"] for v in prof.values()) / (dt * 1e3)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args, model.state_dict())
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

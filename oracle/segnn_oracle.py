@@ -56,3 +56,51 @@ def forward(params, H, num_layers, in_irreps, out_irreps, x, pos, rowptr, src, r
         trace[f"h{l + 1}"] = h
     out = tp(params, "readout", h, A, hid, out_irreps)
     return (out, trace) if return_all else out
+
+
+def forward_torch_cpu(params, H, num_layers, in_irreps, out_irreps, x, pos, rowptr, src):
+    """fp32 torch-CPU pipeline with the reference's op pattern for every tensor product
+    (``l1tp_oracle.forward_faithful``) — the ``cpu_baseline`` of bench.py (kind "port")."""
+    import torch
+
+    hid = f"{H}x0e+{H}x1o"
+    gated = f"{H}x0e+{H}x0e+{H}x1o"
+    rowptr_t = torch.as_tensor(rowptr).long()
+    src_t = torch.as_tensor(src).long()
+    N = rowptr_t.numel() - 1
+    deg = rowptr_t[1:] - rowptr_t[:-1]
+    dst_t = torch.repeat_interleave(torch.arange(N), deg)
+    pos = torch.as_tensor(pos, dtype=torch.float32)
+    rel = pos[src_t] - pos[dst_t]
+    d = rel.norm(dim=1)
+    Y = torch.zeros(len(src_t), 4)
+    Y[:, 0] = 1.0
+    Y[:, 1:] = (3.0 ** 0.5) * rel / d.clamp_min(1e-30)[:, None]
+    A = torch.zeros(N, 4)
+    A[:, 0] = 1.0
+    A[:, 1:].index_add_(0, dst_t, Y[:, 1:])
+    A[:, 1:] /= deg.clamp_min(1)[:, None]
+    P = {k: torch.as_tensor(v) for k, v in params.items()}
+    lays = {}
+
+    def tp(prefix, in1, in2, ii, oi):
+        if (ii, oi) not in lays:
+            lays[(ii, oi)] = O.make_layout(ii, oi)
+        W = {c: P[f"{prefix}.weights_{c}"] for c in O.CLASSES if f"{prefix}.weights_{c}" in P}
+        Nn = {c: P[f"{prefix}.norm_{c}"] for c in O.CLASSES}
+        return O.forward_faithful(lays[(ii, oi)], in1, in2, W, Nn)
+
+    def gate_t(t):
+        s, g, v = t[:, :H], t[:, H:2 * H], t[:, 2 * H:].reshape(-1, H, 3)
+        return torch.cat([torch.nn.functional.silu(s), (torch.sigmoid(g)[:, :, None] * v).reshape(-1, 3 * H)], 1)
+
+    h = tp("embed", torch.as_tensor(x, dtype=torch.float32), A, in_irreps, hid)
+    for l in range(num_layers):
+        p = f"layers.{l}"
+        m = torch.cat([h[dst_t], h[src_t], d[:, None]], 1)
+        m = gate_t(tp(p + ".msg1", m, Y, f"{hid}+{hid}+1x0e", gated))
+        m = gate_t(tp(p + ".msg2", m, Y, hid, gated))
+        a = torch.zeros_like(h).index_add_(0, dst_t, m)
+        u = gate_t(tp(p + ".upd1", torch.cat([h, a], 1), A, f"{hid}+{hid}", gated))
+        h = h + tp(p + ".upd2", u, A, hid, hid)
+    return tp("readout", h, A, hid, out_irreps)

@@ -20,7 +20,7 @@ import torch
 from torch import Tensor
 from torch.nn import Module, Parameter
 
-from . import _lib
+from . import _lib, profiling
 from .irreps import Instruction, Irreps, as_blocks
 
 _CLS = ("l0e", "l0o", "l1e", "l1o")
@@ -270,10 +270,14 @@ class L1TensorProduct(Module):
         with torch.cuda.device(in1.device):
             packed = self._packed_weights(in1.dtype, in1.device)
             stream = torch.cuda.current_stream(in1.device).cuda_stream
+            t0 = profiling.begin() if profiling.enabled() else None
             _lib.check(lib.e3_l1tp_forward(self._get_plan().handle, in1.data_ptr(), in1.stride(0),
                                            in2.data_ptr(), ld2, packed.data_ptr(), out.data_ptr(), out.stride(0),
                                            B, _lib.dtype_code(in1.dtype), int(self.kernel), stream),
                        "e3_l1tp_forward")
+            if t0 is not None:
+                tag = f"l1tp_fwd {self.iri1}->{self.iro} B={B}"
+                profiling.end(tag, B, in1.element_size() * (self.in1_dim + 4 + out.shape[1]) * B, t0)
         return out
 
     def _hip_backward(self, in1, in2, grad_out, need_in1, need_in2, need_w):
