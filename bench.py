@@ -103,21 +103,33 @@ def main():
         raise SystemExit("only l_max=1 is built so far (l_max=2 is the next §8(f) row)")
 
     n = args.particles
-    # Replicas-with-sharded-cloud: the global cloud has world*n particles in [0,world)x[0,1)^2; rank k owns the
-    # slab x in [k,k+1).  (Halo exchange across slabs lands with the sharded model)
+    # One global cloud of world*n particles in [0,world) x [0,1)^2, cut into slabs along x: rank k owns
+    # x in [k,k+1) (generated in place: synthetic data) and ghosts of width r from its slab neighbours.
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     pos = torch.rand(n, 3, device=dev, generator=gen)
+    pos[:, 0] += float(rank)
     x = torch.randn(n, 4, device=dev, generator=gen)
     r = cutoff(n)
     torch.manual_seed(0)
     model = SEGNN("1x0e+1x1o", args.hidden, "1x1o", args.layers).to(dev)
-    lo, hi = [0.0, 0.0, 0.0], [1.0, 1.0, 1.0]
+    halo = None
+    if world > 1:
+        from scalable_e3_gnn_amd.sharding import SlabHalo
+        halo = SlabHalo()
+    lo = [float(rank) - (2 * r if world > 1 else 0.0), 0.0, 0.0]
+    hi = [float(rank) + 1.0 + (2 * r if world > 1 else 0.0), 1.0, 1.0]
 
     def step():
-        g = radius_graph(pos, r, lo, hi)
-        xs = x[g.perm.long()]
+        if halo is None:
+            g = radius_graph(pos, r, lo, hi)
+            xs = x[g.perm.long()]
+        else:
+            lpos, lx = halo.setup(pos, x, float(rank), float(rank + 1), r)   # ghost positions + features
+            g = radius_graph(lpos, r, lo, hi)
+            halo.renumber(g.perm)
+            xs = lx[g.perm.long()]
         with torch.no_grad():
-            out = model(xs, g)
+            out = model(xs, g, halo=halo)
         return g, out
 
     def fence():
@@ -161,7 +173,8 @@ def main():
                                    f"(BASELINE names l_max=2: not built yet, this line is the l_max=1 pipeline)",
                        "particles_per_gpu": n, "edges_per_gpu": g.num_edges, "hidden": args.hidden,
                        "layers": args.layers, "lmax": args.lmax,
-                       "parallelism": "1 process/GPU, independent spatial shards (no halo yet)" if world > 1 else "single GPU"},
+                       "parallelism": (f"spatial slabs x{world}, ghost halo width r, 1 position + {args.layers} feature "
+                                       f"p2p exchanges/step over RCCL") if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "e3::l1tp_fwd_mfma_kernel  [" + dom_tag + "]",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "avg_launch_ms": dom["avg_ms"], "launches": dom["launches"],

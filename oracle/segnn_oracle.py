@@ -36,7 +36,7 @@ def tp(params, prefix, in1, in2, in_irreps, out_irreps):
     return O.forward_closed_form(lay, in1, in2, W, N)
 
 
-def forward(params, H, num_layers, in_irreps, out_irreps, x, pos, rowptr, src, return_all=False):
+def forward(params, H, num_layers, in_irreps, out_irreps, x, pos, rowptr, src, return_all=False, exchange=None):
     """params: dict name -> np array (state_dict of scalable_e3_gnn_amd.segnn.SEGNN)."""
     hid = f"{H}x0e+{H}x1o"
     gated = f"{H}x0e+{H}x0e+{H}x1o"
@@ -45,6 +45,8 @@ def forward(params, H, num_layers, in_irreps, out_irreps, x, pos, rowptr, src, r
     trace = {"Y": Y, "d": d, "A": A, "h0": h}
     for l in range(num_layers):
         p = f"layers.{l}"
+        if exchange is not None:
+            h = exchange(h)
         m = np.concatenate([h[dst], h[src], d[:, None]], 1)
         m = gate(tp(params, p + ".msg1", m, Y, f"{hid}+{hid}+1x0e", gated), H, H)
         m = gate(tp(params, p + ".msg2", m, Y, hid, gated), H, H)

@@ -59,10 +59,16 @@ class SEGNN(nn.Module):
         self.layers = nn.ModuleList([SEGNNLayer(hidden) for _ in range(num_layers)])
         self.readout = L1TensorProduct(hid, self.out_irreps)
 
-    def forward(self, x: torch.Tensor, g: RadiusGraph, geometry=None) -> torch.Tensor:
-        """x [N, in_dim] node features in the graph's (Morton) order -> [N, out_dim] in the same order."""
+    def forward(self, x: torch.Tensor, g: RadiusGraph, geometry=None, halo=None) -> torch.Tensor:
+        """x [N, in_dim] node features in the graph's (Morton) order -> [N, out_dim] in the same order.
+
+        ``halo`` (``sharding.SlabHalo``): when the cloud is spatially sharded, ghost rows of ``h`` are
+        refreshed from their owners before every message-passing layer; only owned rows of the result
+        are meaningful."""
         Y, d, A = geometry if geometry is not None else ops.edge_geometry(g)
         h = self.embed(x, A)
         for layer in self.layers:
+            if halo is not None:
+                h = halo.exchange(h)
             h = layer(h, g, Y, d, A)
         return self.readout(h, A)
