@@ -33,6 +33,13 @@ class SlabHalo:
 
     # -- p2p helper ---------------------------------------------------------------------------------
     def _sendrecv(self, to_left, to_right, from_left, from_right):
+        if to_left.is_cuda and dist.get_backend(self.group) == "gloo":
+            # rehearsal mode (gloo has no device transport): stage through host memory
+            bufs = [t.cpu() for t in (to_left, to_right, from_left, from_right)]
+            self._sendrecv(*bufs)
+            from_left.copy_(bufs[2])
+            from_right.copy_(bufs[3])
+            return
         ops = []  # empty messages are skipped on both ends (sizes were agreed on in `setup`)
         if self.left is not None:
             if to_left.numel():
