@@ -174,6 +174,45 @@ int e3_gate(const float* in, int64_t ld_in, float* out, int64_t ld_out, int64_t 
 int e3_segment_sum(const float* msg, int64_t ld_msg, const int32_t* rowptr, int64_t N, int D,
                    float* agg, int64_t ld_agg, void* stream);
 
+/* =================================================================================================
+ * General SH tensor product, l <= 2 (builder-defined generalisation of the reference operator, which
+ * hard-asserts lmax == 1, l1_tensor_prod.py:13-14).
+ *
+ *   in1  : irreps blocks (l, p, mul), l in {0,1,2}, declaration order = column order (m fastest)
+ *   in2  : real "component" spherical harmonics up to lmax_sh in {1,2}: [Y0 | Y1 xyz | Y2 (5)]
+ *   out[c3, w, m3] = norm * sum_{paths (l1,l2) -> c3} sum_k W_c3[row(path,k), w]
+ *                           sum_{m1,m2} C^{l1 l2 l3}[m1,m2,m3] in1[c1,k,m1] in2[l2,m2]
+ *   classes c = 2*l + (p == -1 ? 1 : 0)  (0e,0o,1e,1o,2e,2o); p1 = p3 * (-1)^l2; triangle rule on (l1,l2,l3)
+ *   weight rows of class c3: paths ordered by (l1, l2) ascending, channels in order of appearance —
+ *   for l <= 1 this is exactly the reference's row order (l1_tensor_prod.py:81-88)
+ *   C: real-basis 3j tensors, unit Frobenius norm, basis/sign convention of oracle/cg.py; for l <= 1 they
+ *   are the reference's constants (l1_tensor_prod.py:91-94) and xyz dot / cross products.
+ * With l <= 1 irreps, lmax_sh = 1 and the same weights/norms, e3_tp_forward == e3_l1tp_forward.
+ * ================================================================================================= */
+typedef struct e3_tp_plan e3_tp_plan;
+int e3_tp_plan_create(const int32_t* in1_blocks, int n_in1, int lmax_sh,
+                      const int32_t* out_blocks, int n_out, e3_tp_plan** plan);
+int e3_tp_plan_destroy(e3_tp_plan* plan);
+int e3_tp_in1_dim(const e3_tp_plan* plan);
+int e3_tp_in2_dim(const e3_tp_plan* plan);
+int e3_tp_out_dim(const e3_tp_plan* plan);
+/* cls in 0..5; rows = sum of in1 multiplicities over the class's paths ("fan-in"), cols = out multiplicity */
+int e3_tp_weight_shape(const e3_tp_plan* plan, int cls, int* rows, int* cols);
+int e3_tp_norm_len(const e3_tp_plan* plan, int cls);
+int64_t e3_tp_packed_bytes(const e3_tp_plan* plan, int dtype);
+int e3_tp_pack_weights(const e3_tp_plan* plan, const void* const weights[6], const void* const norms[6],
+                       int dtype, void* packed, void* stream);
+/* dtype E3_F32 or E3_F64; ld_in2 == 0 broadcasts row 0 of in2 */
+int e3_tp_forward(const e3_tp_plan* plan, const void* in1, int64_t ld_in1, const void* in2, int64_t ld_in2,
+                  const void* packed, void* out, int64_t ld_out, int64_t B, int dtype, void* stream);
+/* SH / geometry for lmax 2: edge_y [E,9], node_a [N,9] (same definitions as e3_edge_geometry, Y2 = sqrt5 b(r^)) */
+int e3_edge_geometry_l2(const float* pos4, const int32_t* rowptr, const int32_t* src, int64_t N,
+                        float* edge_y, float* edge_d, float* node_a, void* stream);
+/* general gate: in = [ns scalars | g gate scalars | gated blocks], block i = mul_i x (2 l_i + 1) with one gate per
+ * channel, gates consumed in block order; out = [silu(s) | sigmoid(gate) * block].  ls/muls: host int arrays. */
+int e3_gate_blocks(const float* in, int64_t ld_in, float* out, int64_t ld_out, int64_t B, int ns,
+                   int nblocks, const int32_t* ls, const int32_t* muls, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,86 @@
+"""numpy fp64 oracle of the general SH tensor product (l <= 2).  TEST INFRASTRUCTURE ONLY.
+Builder-defined contract (include/e3gnn.h "General SH tensor product"); reduces to the reference-pinned
+``l1tp_oracle`` for l <= 1 (checked in tests/test_tp_l2.py).  Parity w.r.t. upstream/e3nn: unpinned."""
+import numpy as np
+
+from . import cg as CG
+from .l1tp_oracle import parse_blocks
+
+CLASSES = ("l0e", "l0o", "l1e", "l1o", "l2e", "l2o")
+
+
+def cls_of(l, p):
+    return 2 * l + (0 if p == 1 else 1)
+
+
+def class_columns(blocks):
+    """per class: array [channels, 2l+1] of column indices, channels in order of appearance"""
+    cols = {c: [] for c in range(6)}
+    i = 0
+    for l, p, mul in blocks:
+        for k in range(mul):
+            cols[cls_of(l, p)].append(list(range(i + k * (2 * l + 1), i + (k + 1) * (2 * l + 1))))
+        i += (2 * l + 1) * mul
+    return {c: np.asarray(v, dtype=np.int64).reshape(len(v), 2 * (c >> 1) + 1) for c, v in cols.items()}
+
+
+def paths(c3, n_in, lmax_sh):
+    l3, p3 = c3 >> 1, (1 if c3 % 2 == 0 else -1)
+    out = []
+    for l1 in range(3):
+        for l2 in range(lmax_sh + 1):
+            if abs(l1 - l2) <= l3 <= l1 + l2:
+                c1 = cls_of(l1, p3 * (-1) ** l2)
+                if n_in[c1] > 0:
+                    out.append((c1, l1, l2))
+    return out
+
+
+def shapes(in1_irreps, out_irreps, lmax_sh):
+    ib, ob = parse_blocks(in1_irreps), parse_blocks(out_irreps)
+    ic, oc = class_columns(ib), class_columns(ob)
+    n_in = {c: len(ic[c]) for c in range(6)}
+    res = {}
+    for c3 in range(6):
+        M = len(oc[c3])
+        K = sum(n_in[c1] for c1, _, _ in paths(c3, n_in, lmax_sh))
+        res[CLASSES[c3]] = (K, M) if (K > 0 and M > 0) else None
+    return res
+
+
+def default_norms(in1_irreps, out_irreps, lmax_sh):
+    sh = shapes(in1_irreps, out_irreps, lmax_sh)
+    oc = class_columns(parse_blocks(out_irreps))
+    out = {}
+    for c3, name in enumerate(CLASSES):
+        l = c3 >> 1
+        K = sh[name][0] if sh[name] else 0
+        out[name] = np.full(len(oc[c3]) * (2 * l + 1), np.float32(np.sqrt((2 * l + 1) / K) if K else 1.0))
+    return out
+
+
+def forward(in1_irreps, out_irreps, lmax_sh, in1, in2, W, norms):
+    ib, ob = parse_blocks(in1_irreps), parse_blocks(out_irreps)
+    ic, oc = class_columns(ib), class_columns(ob)
+    n_in = {c: len(ic[c]) for c in range(6)}
+    in1 = np.asarray(in1, np.float64)
+    in2 = np.asarray(in2, np.float64)
+    B = in1.shape[0]
+    in2 = np.broadcast_to(in2, (B, in2.shape[1]))
+    out = np.zeros((B, sum((2 * l + 1) * m for l, _, m in ob)))
+    for c3, name in enumerate(CLASSES):
+        if len(oc[c3]) == 0:
+            continue
+        l3 = c3 >> 1
+        feats = []
+        for c1, l1, l2 in paths(c3, n_in, lmax_sh):
+            x = in1[:, ic[c1]]                                    # [B, n, 2l1+1]
+            y = in2[:, l2 * l2:(l2 + 1) * (l2 + 1)]               # [B, 2l2+1]
+            feats.append(np.einsum("bkm,bn,mnq->bkq", x, y, CG.cg(l1, l2, l3)))
+        if not feats:
+            continue
+        F = np.concatenate(feats, 1)                              # [B, K, 2l3+1]
+        o = np.einsum("bkq,kw->bwq", F, np.asarray(W[name], np.float64))
+        o = o.reshape(B, -1) * np.asarray(norms[name], np.float64)
+        out[:, oc[c3].reshape(-1)] = o
+    return out

@@ -48,6 +48,20 @@ SIGNATURES = {
                                  c_int64, c_void_p]),
     "e3_gate": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p]),
     "e3_segment_sum": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p]),
+    "e3_tp_plan_create": (c_int, [POINTER(c_int32), c_int, c_int, POINTER(c_int32), c_int, POINTER(c_void_p)]),
+    "e3_tp_plan_destroy": (c_int, [c_void_p]),
+    "e3_tp_in1_dim": (c_int, [c_void_p]),
+    "e3_tp_in2_dim": (c_int, [c_void_p]),
+    "e3_tp_out_dim": (c_int, [c_void_p]),
+    "e3_tp_weight_shape": (c_int, [c_void_p, c_int, POINTER(c_int), POINTER(c_int)]),
+    "e3_tp_norm_len": (c_int, [c_void_p, c_int]),
+    "e3_tp_packed_bytes": (c_int64, [c_void_p, c_int]),
+    "e3_tp_pack_weights": (c_int, [c_void_p, c_void_p * 6, c_void_p * 6, c_int, c_void_p, c_void_p]),
+    "e3_tp_forward": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64,
+                              c_int, c_void_p]),
+    "e3_edge_geometry_l2": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "e3_gate_blocks": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, POINTER(c_int32),
+                               POINTER(c_int32), c_void_p]),
     "e3_l1tp_backward": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, VoidP4, VoidP4, c_void_p, c_int64,
                                  c_void_p, c_int64, c_void_p, VoidP4, c_void_p, c_int64, c_int, c_void_p]),
 }

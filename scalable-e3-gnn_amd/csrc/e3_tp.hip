@@ -1,0 +1,326 @@
+// General SH tensor product for l <= 2 (builder-defined; contract in include/e3gnn.h).  This file:
+// host plan, weight packing and the generic FMA kernel (fp32 / fp64).  It contracts the channel index
+// with W first (T[m1] = sum_k W[k,w] x[k,m1]) and applies the coupling tensor and Y afterwards.
+#include "e3_common.h"
+#include "cg_tables.h"
+
+#include <algorithm>
+
+namespace e3 {
+
+struct TpPath { int c1, l1, l2, wrow; };
+
+struct TpDev {
+  int D1, Dout, Dy, lmax_sh;
+  int n[6], M[6], cbase[6], obase[6], ocol_off[6], npath[6], poff[6], K[6];
+  int64_t woff[6];
+  int64_t normcol_off, packed_elems;
+  const int32_t* cpos;
+  const int32_t* ocol;
+  const TpPath* paths;
+};
+
+}  // namespace e3
+
+struct e3_tp_plan {
+  e3::TpDev dev;
+  std::vector<int32_t> h_tables;  // [cpos (D1) | ocol (sum M)]
+  std::vector<e3::TpPath> h_paths;
+  int32_t* d_tables = nullptr;
+  e3::TpPath* d_paths = nullptr;
+  std::mutex mu;
+};
+
+namespace e3 {
+
+template <int L1, int L2, int L3, typename A>
+__device__ __forceinline__ void tp_path_apply(const A* __restrict__ x, int n, const A* __restrict__ W, int M,
+                                              const A* __restrict__ y, A (&o)[5]) {
+  if constexpr (CG<L1, L2, L3>::valid) {
+    constexpr int D1 = 2 * L1 + 1, D2 = 2 * L2 + 1, D3 = 2 * L3 + 1;
+    A T[D1];
+#pragma unroll
+    for (int a = 0; a < D1; ++a) T[a] = 0;
+    for (int k = 0; k < n; ++k) {
+      const A wk = W[(int64_t)k * M];
+#pragma unroll
+      for (int a = 0; a < D1; ++a) T[a] += x[k * D1 + a] * wk;
+    }
+#pragma unroll
+    for (int a = 0; a < D1; ++a)
+#pragma unroll
+      for (int b = 0; b < D2; ++b)
+#pragma unroll
+        for (int c = 0; c < D3; ++c)
+          if (CG<L1, L2, L3>::v[a][b][c] != 0.0) o[c] += A(CG<L1, L2, L3>::v[a][b][c]) * T[a] * y[b];
+  }
+}
+
+template <typename T, int R>
+__global__ __launch_bounds__(256) void tp_fwd_generic_kernel(const T* __restrict__ in1, int64_t ld1,
+                                                             const T* __restrict__ in2, int64_t ld2,
+                                                             const typename AccOf<T>::type* __restrict__ packed,
+                                                             T* __restrict__ out, int64_t ldo, int64_t B, TpDev p) {
+  using A = typename AccOf<T>::type;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  A* xs = reinterpret_cast<A*>(smem_raw);
+  A* ys = xs + (size_t)R * p.D1;
+  const int tid = threadIdx.x;
+  int Mtot = 0;
+  for (int c = 0; c < 6; ++c) Mtot += p.M[c];
+  const A* normcol = packed + p.normcol_off;
+  const int64_t ntiles = (B + R - 1) / R;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t row0 = tile * R;
+    for (int i = tid; i < R * p.D1; i += 256) {
+      int r = i / p.D1, d = i - r * p.D1;
+      int64_t row = row0 + r;
+      xs[r * p.D1 + p.cpos[d]] = row < B ? to_acc(in1[row * ld1 + d]) : A(0);
+    }
+    for (int i = tid; i < R * p.Dy; i += 256) {
+      int r = i / p.Dy, d = i - r * p.Dy;
+      int64_t row = row0 + r;
+      ys[i] = row < B ? to_acc(in2[row * ld2 + d]) : A(0);
+    }
+    __syncthreads();
+    for (int i = tid; i < R * Mtot; i += 256) {
+      int r = i / Mtot, w = i - r * Mtot;
+      int64_t row = row0 + r;
+      if (row >= B) continue;
+      int c3 = 0;
+      while (w >= p.M[c3]) { w -= p.M[c3]; ++c3; }
+      const int l3 = c3 >> 1, M = p.M[c3];
+      const A* x = xs + r * p.D1;
+      const A* y = ys + r * p.Dy;
+      A o[5] = {0, 0, 0, 0, 0};
+      for (int pi = 0; pi < p.npath[c3]; ++pi) {
+        const TpPath P = p.paths[p.poff[c3] + pi];
+        const A* xc = x + p.cbase[P.c1];
+        const A* W = packed + p.woff[c3] + (int64_t)P.wrow * M + w;
+        const A* yl = y + P.l2 * P.l2;  // offsets 0, 1, 4
+        const int n = p.n[P.c1];
+        switch (P.l1 * 9 + P.l2 * 3 + l3) {
+#define E3_CASE(a, b, c) case a * 9 + b * 3 + c: tp_path_apply<a, b, c, A>(xc, n, W, M, yl, o); break;
+          E3_CASE(0, 0, 0) E3_CASE(0, 1, 1) E3_CASE(0, 2, 2) E3_CASE(1, 0, 1) E3_CASE(1, 1, 0) E3_CASE(1, 1, 1)
+          E3_CASE(1, 1, 2) E3_CASE(1, 2, 1) E3_CASE(1, 2, 2) E3_CASE(2, 0, 2) E3_CASE(2, 1, 1) E3_CASE(2, 1, 2)
+          E3_CASE(2, 2, 0) E3_CASE(2, 2, 1) E3_CASE(2, 2, 2)
+#undef E3_CASE
+          default: break;
+        }
+      }
+      const int oc = p.ocol[p.ocol_off[c3] + w];
+      T* dst = out + row * ldo + oc;
+      for (int m = 0; m < 2 * l3 + 1; ++m) dst[m] = from_acc<T, A>(o[m] * normcol[oc + m]);
+    }
+    __syncthreads();
+  }
+}
+
+template <typename T>
+__global__ void tp_pack_kernel(const T* w0, const T* w1, const T* w2, const T* w3, const T* w4, const T* w5,
+                               const T* n0, const T* n1, const T* n2, const T* n3, const T* n4, const T* n5,
+                               typename AccOf<T>::type* packed, TpDev p) {
+  using A = typename AccOf<T>::type;
+  const T* w[6] = {w0, w1, w2, w3, w4, w5};
+  const T* nr[6] = {n0, n1, n2, n3, n4, n5};
+  int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int c = 0; c < 6; ++c) {
+    int64_t nw = (int64_t)p.K[c] * p.M[c];
+    for (int64_t i = tid; i < nw; i += stride) packed[p.woff[c] + i] = w[c] ? to_acc(w[c][i]) : A(0);
+    int width = 2 * (c >> 1) + 1;
+    for (int64_t i = tid; i < (int64_t)p.M[c] * width; i += stride) {
+      int m = (int)(i / width), comp = (int)(i - (int64_t)m * width);
+      packed[p.normcol_off + p.ocol[p.ocol_off[c] + m] + comp] = nr[c] ? to_acc(nr[c][i]) : A(1);
+    }
+  }
+}
+
+static int tp_ensure_device(const e3_tp_plan* cplan) {
+  auto* P = const_cast<e3_tp_plan*>(cplan);
+  std::lock_guard<std::mutex> lock(P->mu);
+  if (P->d_tables) return E3_OK;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return E3_ERR_NO_DEVICE;
+  int32_t* d = nullptr;
+  E3_HIP_CHECK(hipMalloc((void**)&d, P->h_tables.size() * sizeof(int32_t)));
+  E3_HIP_CHECK(hipMemcpy(d, P->h_tables.data(), P->h_tables.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  size_t np = std::max<size_t>(P->h_paths.size(), 1);
+  E3_HIP_CHECK(hipMalloc((void**)&P->d_paths, np * sizeof(TpPath)));
+  if (!P->h_paths.empty())
+    E3_HIP_CHECK(hipMemcpy(P->d_paths, P->h_paths.data(), P->h_paths.size() * sizeof(TpPath), hipMemcpyHostToDevice));
+  P->dev.cpos = d;
+  P->dev.ocol = d + P->dev.D1;
+  P->dev.paths = P->d_paths;
+  P->d_tables = d;
+  return E3_OK;
+}
+
+template <typename T>
+static int tp_launch_fwd(const e3_tp_plan* plan, const void* in1, int64_t ld1, const void* in2, int64_t ld2,
+                         const void* packed, void* out, int64_t ldo, int64_t B, hipStream_t s) {
+  using A = typename AccOf<T>::type;
+  constexpr int R = 16;
+  size_t smem = (size_t)R * (plan->dev.D1 + plan->dev.Dy) * sizeof(A);
+  if (smem > 160 * 1024) return E3_ERR_UNSUPPORTED;
+  auto kern = tp_fwd_generic_kernel<T, R>;
+  if (smem > 64 * 1024)
+    E3_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  int grid = (int)std::min<int64_t>((B + R - 1) / R, 256 * 8);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, (const T*)in1, ld1, (const T*)in2, ld2, (const A*)packed,
+                     (T*)out, ldo, B, plan->dev);
+  E3_HIP_CHECK(hipGetLastError());
+  return E3_OK;
+}
+
+}  // namespace e3
+
+using namespace e3;
+
+extern "C" {
+
+int e3_tp_plan_create(const int32_t* in1_blocks, int n_in1, int lmax_sh, const int32_t* out_blocks, int n_out,
+                      e3_tp_plan** plan_out) {
+  if (!in1_blocks || !out_blocks || n_in1 <= 0 || n_out <= 0 || !plan_out) return E3_ERR_INVALID_ARG;
+  if (lmax_sh < 1 || lmax_sh > 2) return E3_ERR_BAD_IRREPS;
+  auto* P = new e3_tp_plan();
+  TpDev& d = P->dev;
+  d.lmax_sh = lmax_sh;
+  d.Dy = (lmax_sh + 1) * (lmax_sh + 1);
+  for (int c = 0; c < 6; ++c) d.n[c] = d.M[c] = 0;
+  struct Blk { int l, p, mul, col; };
+  std::vector<Blk> bi, bo;
+  auto parse = [&](const int32_t* b, int n, std::vector<Blk>& v, int* dim) {
+    int col = 0;
+    for (int i = 0; i < n; ++i) {
+      int l = b[3 * i], p = b[3 * i + 1], mul = b[3 * i + 2];
+      if (l < 0 || l > 2 || (p != 1 && p != -1) || mul < 0) return false;
+      v.push_back({l, p, mul, col});
+      col += (2 * l + 1) * mul;
+    }
+    *dim = col;
+    return true;
+  };
+  if (!parse(in1_blocks, n_in1, bi, &d.D1) || !parse(out_blocks, n_out, bo, &d.Dout)) {
+    delete P;
+    return E3_ERR_BAD_IRREPS;
+  }
+  auto cls = [](int l, int p) { return 2 * l + (p == 1 ? 0 : 1); };
+  for (auto& b : bi) d.n[cls(b.l, b.p)] += b.mul;
+  for (auto& b : bo) d.M[cls(b.l, b.p)] += b.mul;
+  int pos = 0;
+  for (int c = 0; c < 6; ++c) { d.cbase[c] = pos; pos += d.n[c] * (2 * (c >> 1) + 1); }
+  pos = 0;
+  for (int c = 0; c < 6; ++c) { d.obase[c] = pos; pos += d.M[c] * (2 * (c >> 1) + 1); }
+  std::vector<int32_t> tables(d.D1, 0);
+  {
+    int fill[6] = {0, 0, 0, 0, 0, 0};
+    for (auto& b : bi) {
+      int c = cls(b.l, b.p), w = 2 * b.l + 1;
+      for (int i = 0; i < b.mul * w; ++i) tables[b.col + i] = d.cbase[c] + fill[c] + i;
+      fill[c] += b.mul * w;
+    }
+  }
+  int off = 0;
+  for (int c = 0; c < 6; ++c) {
+    d.ocol_off[c] = off;
+    for (auto& b : bo)
+      if (cls(b.l, b.p) == c)
+        for (int i = 0; i < b.mul; ++i) tables.push_back(b.col + i * (2 * b.l + 1));
+    off += d.M[c];
+  }
+  tables.push_back(0);
+  P->h_tables = std::move(tables);
+  // paths per out class, ordered by (l1, l2)
+  int64_t wpos = 0;
+  for (int c3 = 0; c3 < 6; ++c3) {
+    const int l3 = c3 >> 1, p3 = (c3 & 1) ? -1 : 1;
+    d.poff[c3] = (int)P->h_paths.size();
+    d.npath[c3] = 0;
+    int wrow = 0;
+    for (int l1 = 0; l1 <= 2; ++l1)
+      for (int l2 = 0; l2 <= lmax_sh; ++l2) {
+        if (l3 < std::abs(l1 - l2) || l3 > l1 + l2) continue;
+        const int p2 = (l2 & 1) ? -1 : 1;
+        const int c1 = cls(l1, p3 * p2);
+        if (d.n[c1] == 0) continue;
+        if (d.M[c3] > 0) {
+          P->h_paths.push_back({c1, l1, l2, wrow});
+          d.npath[c3]++;
+        }
+        wrow += d.n[c1];
+      }
+    d.K[c3] = d.M[c3] > 0 ? wrow : 0;
+    d.woff[c3] = wpos;
+    wpos += (int64_t)d.K[c3] * d.M[c3];
+  }
+  d.normcol_off = wpos;
+  d.packed_elems = wpos + d.Dout;
+  *plan_out = P;
+  return E3_OK;
+}
+
+int e3_tp_plan_destroy(e3_tp_plan* P) {
+  if (!P) return E3_OK;
+  if (P->d_tables) (void)hipFree(P->d_tables);
+  if (P->d_paths) (void)hipFree(P->d_paths);
+  delete P;
+  return E3_OK;
+}
+
+int e3_tp_in1_dim(const e3_tp_plan* p) { return p ? p->dev.D1 : -1; }
+int e3_tp_in2_dim(const e3_tp_plan* p) { return p ? p->dev.Dy : -1; }
+int e3_tp_out_dim(const e3_tp_plan* p) { return p ? p->dev.Dout : -1; }
+int e3_tp_weight_shape(const e3_tp_plan* p, int cls, int* rows, int* cols) {
+  if (!p || cls < 0 || cls > 5 || !rows || !cols) return E3_ERR_INVALID_ARG;
+  bool present = p->dev.K[cls] > 0 && p->dev.M[cls] > 0;
+  *rows = present ? p->dev.K[cls] : 0;
+  *cols = present ? p->dev.M[cls] : 0;
+  return E3_OK;
+}
+int e3_tp_norm_len(const e3_tp_plan* p, int cls) {
+  return (p && cls >= 0 && cls < 6) ? p->dev.M[cls] * (2 * (cls >> 1) + 1) : -1;
+}
+int64_t e3_tp_packed_bytes(const e3_tp_plan* p, int dtype) {
+  if (!p || (dtype != E3_F32 && dtype != E3_F64)) return -1;
+  return (p->dev.packed_elems + 64) * (dtype == E3_F64 ? 8 : 4);
+}
+
+int e3_tp_pack_weights(const e3_tp_plan* plan, const void* const w[6], const void* const n[6], int dtype, void* packed,
+                       void* stream) {
+  if (!plan || !w || !packed || (dtype != E3_F32 && dtype != E3_F64)) return E3_ERR_INVALID_ARG;
+  for (int c = 0; c < 6; ++c)
+    if (plan->dev.M[c] > 0 && plan->dev.K[c] > 0 && !w[c]) return E3_ERR_MISSING_WEIGHT;
+  int st = tp_ensure_device(plan);
+  if (st != E3_OK) return st;
+  const void* nn[6] = {0, 0, 0, 0, 0, 0};
+  if (n)
+    for (int c = 0; c < 6; ++c) nn[c] = plan->dev.M[c] > 0 ? n[c] : nullptr;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == E3_F32)
+    hipLaunchKernelGGL(tp_pack_kernel<float>, dim3(64), dim3(256), 0, s, (const float*)w[0], (const float*)w[1],
+                       (const float*)w[2], (const float*)w[3], (const float*)w[4], (const float*)w[5],
+                       (const float*)nn[0], (const float*)nn[1], (const float*)nn[2], (const float*)nn[3],
+                       (const float*)nn[4], (const float*)nn[5], (float*)packed, plan->dev);
+  else
+    hipLaunchKernelGGL(tp_pack_kernel<double>, dim3(64), dim3(256), 0, s, (const double*)w[0], (const double*)w[1],
+                       (const double*)w[2], (const double*)w[3], (const double*)w[4], (const double*)w[5],
+                       (const double*)nn[0], (const double*)nn[1], (const double*)nn[2], (const double*)nn[3],
+                       (const double*)nn[4], (const double*)nn[5], (double*)packed, plan->dev);
+  E3_HIP_CHECK(hipGetLastError());
+  return E3_OK;
+}
+
+int e3_tp_forward(const e3_tp_plan* plan, const void* in1, int64_t ld1, const void* in2, int64_t ld2,
+                  const void* packed, void* out, int64_t ldo, int64_t B, int dtype, void* stream) {
+  if (!plan || B < 0 || (dtype != E3_F32 && dtype != E3_F64)) return E3_ERR_INVALID_ARG;
+  if (B == 0) return E3_OK;
+  if (!in1 || !in2 || !packed || !out) return E3_ERR_INVALID_ARG;
+  if (ld1 < plan->dev.D1 || ldo < plan->dev.Dout || (ld2 != 0 && ld2 < plan->dev.Dy)) return E3_ERR_INVALID_ARG;
+  int st = tp_ensure_device(plan);
+  if (st != E3_OK) return st;
+  hipStream_t s = (hipStream_t)stream;
+  return dtype == E3_F32 ? tp_launch_fwd<float>(plan, in1, ld1, in2, ld2, packed, out, ldo, B, s)
+                         : tp_launch_fwd<double>(plan, in1, ld1, in2, ld2, packed, out, ldo, B, s);
+}
+
+}  // extern "C"

@@ -20,15 +20,17 @@ def _stream(t):
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
-def edge_geometry(g: RadiusGraph, want_dist=True, want_node_attr=True):
-    """-> Y [E,4], d [E] | None, A [N,4] | None"""
+def edge_geometry(g: RadiusGraph, want_dist=True, want_node_attr=True, lmax: int = 1):
+    """-> Y [E,(lmax+1)^2], d [E] | None, A [N,(lmax+1)^2] | None"""
     _check(g.pos4, "pos4")
     N, E, dev = g.rowptr.numel() - 1, g.num_edges, g.pos4.device
-    Y = torch.empty((E, 4), dtype=torch.float32, device=dev)
+    ny = (lmax + 1) ** 2
+    Y = torch.empty((E, ny), dtype=torch.float32, device=dev)
     d = torch.empty(E, dtype=torch.float32, device=dev) if want_dist else None
-    A = torch.empty((N, 4), dtype=torch.float32, device=dev) if want_node_attr else None
+    A = torch.empty((N, ny), dtype=torch.float32, device=dev) if want_node_attr else None
+    fn = {1: "e3_edge_geometry", 2: "e3_edge_geometry_l2"}[lmax]
     with torch.cuda.device(dev):
-        _lib.check(_lib.load().e3_edge_geometry(g.pos4.data_ptr(), g.rowptr.data_ptr(), g.src.data_ptr(), N,
+        _lib.check(getattr(_lib.load(), fn)(g.pos4.data_ptr(), g.rowptr.data_ptr(), g.src.data_ptr(), N,
                                                 Y.data_ptr(), d.data_ptr() if d is not None else None,
                                                 A.data_ptr() if A is not None else None, _stream(Y)),
                    "e3_edge_geometry")
@@ -81,3 +83,23 @@ def segment_sum(msg: torch.Tensor, g: RadiusGraph) -> torch.Tensor:
         _lib.check(_lib.load().e3_segment_sum(msg.data_ptr(), msg.stride(0), g.rowptr.data_ptr(), N, D,
                                               agg.data_ptr(), agg.stride(0), _stream(msg)), "e3_segment_sum")
     return agg
+
+
+def gate_blocks(x: torch.Tensor, ns: int, blocks) -> torch.Tensor:
+    """x = [ns scalars | one gate per gated channel | gated blocks]; blocks = [(l, mul), ...]
+    -> [silu(scalars) | sigmoid(gate) * block]"""
+    import ctypes
+    _check(x, "x")
+    if x.stride(-1) != 1:
+        x = x.contiguous()
+    B = x.shape[0]
+    ng = sum(m for _, m in blocks)
+    wide = sum(m * (2 * l + 1) for l, m in blocks)
+    assert x.shape[1] == ns + ng + wide, (x.shape, ns, blocks)
+    out = torch.empty((B, ns + wide), dtype=torch.float32, device=x.device)
+    ls = (ctypes.c_int32 * len(blocks))(*[l for l, _ in blocks])
+    ms = (ctypes.c_int32 * len(blocks))(*[m for _, m in blocks])
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().e3_gate_blocks(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), B, ns,
+                                              len(blocks), ls, ms, _stream(x)), "e3_gate_blocks")
+    return out

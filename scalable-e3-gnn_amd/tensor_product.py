@@ -1,0 +1,117 @@
+"""``SHTensorProduct`` — fully-connected tensor product of a feature (l <= 2) with the spherical
+harmonics of an edge (lmax_sh in {1,2}); builder-defined generalisation of the reference's
+``L1TensorProduct`` (which asserts lmax == 1, `L1TP.py:13-14`).  Contract: include/e3gnn.h
+("General SH tensor product").  Same conventions as the reference where they overlap: one weight
+matrix per output (l,p) class with rows in forward-concat order, ``U[-1,1]`` init, per-class norm
+buffers ``sqrt((2l+1)/fan_in)`` ("component" x "element"), CG constants of `L1TP.py:91-94` for l <= 1.
+Forward only (fp32 / fp64), ROCm tensors only, no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes
+from math import sqrt
+
+import torch
+from torch import nn
+
+from . import _lib, profiling
+from .irreps import Irreps, as_blocks
+
+CLASSES = ("l0e", "l0o", "l1e", "l1o", "l2e", "l2o")
+
+
+class SHTensorProduct(nn.Module):
+    def __init__(self, in1_irreps, out_irreps, lmax_sh: int = 2):
+        super().__init__()
+        self.iri1 = Irreps(in1_irreps) if isinstance(in1_irreps, str) else in1_irreps
+        self.iro = Irreps(out_irreps) if isinstance(out_irreps, str) else out_irreps
+        self.iri2 = Irreps.spherical_harmonics(lmax_sh)
+        self.lmax_sh = lmax_sh
+        lib = _lib.load()
+        a, na = _lib.blocks_array(as_blocks(self.iri1))
+        b, nb = _lib.blocks_array(as_blocks(self.iro))
+        self._handle = ctypes.c_void_p()
+        _lib.check(lib.e3_tp_plan_create(a, na, lmax_sh, b, nb, ctypes.byref(self._handle)), "e3_tp_plan_create")
+        self._destroy = lib.e3_tp_plan_destroy
+        self.in1_dim = lib.e3_tp_in1_dim(self._handle)
+        self.in2_dim = lib.e3_tp_in2_dim(self._handle)
+        self.out_dim = lib.e3_tp_out_dim(self._handle)
+        for ci, c in enumerate(CLASSES):
+            rows, cols = ctypes.c_int(), ctypes.c_int()
+            lib.e3_tp_weight_shape(self._handle, ci, ctypes.byref(rows), ctypes.byref(cols))
+            nlen = lib.e3_tp_norm_len(self._handle, ci)
+            if rows.value > 0 and cols.value > 0:
+                setattr(self, "weights_" + c, nn.Parameter(torch.rand((rows.value, cols.value)) * 2 - 1))
+            l = ci >> 1
+            val = sqrt((2 * l + 1) / rows.value) if rows.value > 0 else 1.0
+            self.register_buffer("norm_" + c, torch.full((nlen,), val))
+        self._packed = None
+        self._packed_key = None
+
+    def __del__(self):
+        try:
+            if self._handle:
+                self._destroy(self._handle)
+                self._handle = None
+        except Exception:
+            pass
+
+    def _tensors(self):
+        ws = [getattr(self, "weights_" + c, None) for c in CLASSES]
+        ns = [getattr(self, "norm_" + c) for c in CLASSES]
+        return ws, ns
+
+    def _packed_weights(self, dtype, device):
+        ws, ns = self._tensors()
+        key = (dtype, device) + tuple((t.data_ptr(), t._version) if t is not None else None for t in ws + ns)
+        if self._packed is not None and self._packed_key == key:
+            return self._packed
+        lib = _lib.load()
+        code = _lib.dtype_code(dtype)
+        for t in ws + ns:
+            if t is not None and t.numel() and (t.dtype != dtype or t.device != device):
+                raise RuntimeError(f"SHTensorProduct: parameter {t.dtype}/{t.device} vs input {dtype}/{device}")
+        nbytes = lib.e3_tp_packed_bytes(self._handle, code)
+        if nbytes < 0:
+            raise RuntimeError(f"SHTensorProduct supports float32/float64, got {dtype}")
+        packed = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        P6 = ctypes.c_void_p * 6
+        ptr = lambda t: t.data_ptr() if (t is not None and t.numel()) else None
+        wsc = [w.detach().contiguous() if w is not None else None for w in ws]
+        stream = torch.cuda.current_stream(device).cuda_stream
+        _lib.check(lib.e3_tp_pack_weights(self._handle, P6(*map(ptr, wsc)), P6(*map(ptr, ns)), code,
+                                          packed.data_ptr(), stream), "e3_tp_pack_weights")
+        self._packed, self._packed_key = packed, key
+        return packed
+
+    def forward(self, in1: torch.Tensor, in2: torch.Tensor) -> torch.Tensor:
+        torch._assert(in1.shape[-1] == self.in1_dim,
+                      f"Incorrect last dimension for in1 = {in1.shape[-1]}, required is {self.in1_dim}")
+        torch._assert(in2.shape[-1] == self.in2_dim,
+                      f"Incorrect last dimension for in2 = {in2.shape[-1]}, required is {self.in2_dim}")
+        if not in1.is_cuda:
+            raise RuntimeError("SHTensorProduct runs on ROCm tensors only; there is no CPU path")
+        if torch.is_grad_enabled() and (in1.requires_grad or in2.requires_grad or
+                                        any(p.requires_grad for p in self.parameters())):
+            raise NotImplementedError("SHTensorProduct is forward-only for now: call it under torch.no_grad()")
+        B = in1.shape[0]
+        out = torch.empty((B, self.out_dim), dtype=in1.dtype, device=in1.device)
+        if B == 0:
+            return out
+        if in1.stride(-1) != 1:
+            in1 = in1.contiguous()
+        if in2.stride(-1) != 1:
+            in2 = in2.contiguous()
+        ld2 = 0 if (in2.shape[0] == 1 and B != 1) else in2.stride(0)
+        lib = _lib.load()
+        with torch.cuda.device(in1.device):
+            packed = self._packed_weights(in1.dtype, in1.device)
+            stream = torch.cuda.current_stream(in1.device).cuda_stream
+            t0 = profiling.begin() if profiling.enabled() else None
+            _lib.check(lib.e3_tp_forward(self._handle, in1.data_ptr(), in1.stride(0), in2.data_ptr(), ld2,
+                                         packed.data_ptr(), out.data_ptr(), out.stride(0), B,
+                                         _lib.dtype_code(in1.dtype), stream), "e3_tp_forward")
+            if t0 is not None:
+                profiling.end(f"tp_fwd(l<=2) {self.iri1}->{self.iro} B={B}", B,
+                              in1.element_size() * (self.in1_dim + self.in2_dim + self.out_dim) * B, t0)
+        return out

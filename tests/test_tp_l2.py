@@ -1,0 +1,126 @@
+"""General SH tensor product (l <= 2): CG tables, reduction to the reference-pinned L1TP, GPU parity
+with the numpy oracle, equivariance.  Builder-defined (parity unpinned w.r.t. upstream)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cg as CG
+from oracle import l1tp_oracle as O1
+from oracle import tp_oracle as T
+
+
+def test_cg_tables_match_reference_constants_and_are_invariant():
+    assert CG.cg(0, 0, 0)[0, 0, 0] == pytest.approx(1.0)
+    assert np.allclose(CG.cg(1, 1, 0)[:, :, 0], np.eye(3) * O1.C3, atol=1e-14)
+    assert np.allclose(CG.cg(0, 1, 1)[0], np.eye(3) * O1.C3, atol=1e-14)
+    eps = np.zeros((3, 3, 3))
+    for i, j, k in [(0, 1, 2), (1, 2, 0), (2, 0, 1)]:
+        eps[i, j, k], eps[j, i, k] = 1, -1
+    assert np.allclose(CG.cg(1, 1, 1), eps * O1.C6, atol=1e-14)
+    rng = np.random.default_rng(5)
+    R = CG.random_rotation(rng)
+    for (l1, l2, l3), C in CG.all_tables().items():
+        D1, D2, D3 = (CG.rotation_matrices(l, R) for l in (l1, l2, l3))
+        assert np.allclose(np.einsum("ai,bj,ck,ijk->abc", D1, D2, D3, C), C, atol=1e-12)
+        assert abs((C * C).sum() - 1) < 1e-12
+    assert CG.cg(0, 1, 2) is None and len(CG.all_tables()) == 15
+
+
+def test_generated_header_matches_oracle_tables():
+    import os, re
+    from conftest import REPO
+    text = open(os.path.join(REPO, "scalable-e3-gnn_amd", "csrc", "cg_tables.h")).read()
+    for (l1, l2, l3), C in CG.all_tables().items():
+        m = re.search(rf"CG<{l1},{l2},{l3}> .*?= (\{{.*?\}});", text)
+        vals = np.array([float(v) for v in re.findall(r"-?\d+\.\d+(?:e-?\d+)?", m.group(1))])
+        assert np.array_equal(vals, C.reshape(-1)), (l1, l2, l3)
+
+
+def test_oracle_reduces_to_l1tp_oracle():
+    rng = np.random.default_rng(0)
+    for in1, out in (("8x0e+8x1o", "8x0e+8x1o"), ("3x0e+2x0o+4x1o+5x1e", "6x0e+2x0o+3x1e+7x1o"),
+                     ("2x1o+3x0e+1x1e+2x0e+2x1o+1x0o", "1x1e+2x0e+2x1o+1x0o+3x1o+2x0e")):
+        lay = O1.make_layout(in1, out)
+        sh = T.shapes(in1, out, 1)
+        W = {}
+        for c in O1.CLASSES:
+            assert (lay.wshape[c] or None) == (sh[c] or None)
+            if lay.wshape[c]:
+                W[c] = rng.uniform(-1, 1, lay.wshape[c])
+        x, y = rng.normal(size=(7, lay.in1_dim)), rng.normal(size=(7, 4))
+        norms = {c: rng.uniform(0.5, 1.5, len(lay.o[c])) for c in O1.CLASSES}
+        a = O1.forward_closed_form(lay, x, y, W, norms)
+        b = T.forward(in1, out, 1, x, y, W, {**{c: np.zeros(0) for c in T.CLASSES}, **norms})
+        assert np.abs(a - b).max() < 1e-13
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("in1,out,lmax_sh,dtype", [
+    ("8x0e+8x1o", "8x0e+8x1o", 1, "float32"),
+    ("8x0e+8x1o+8x2e", "8x0e+8x1o+8x2e", 2, "float64"),
+    ("8x0e+8x1o+8x2e", "8x0e+8x1o+8x2e", 2, "float32"),
+    ("3x0e+2x0o+4x1o+5x1e+2x2e+3x2o", "6x0e+2x0o+3x1e+7x1o+2x2o+3x2e", 2, "float64"),
+    ("32x0e+32x1o+32x2e+32x0e+32x1o+32x2e+1x0e", "96x0e+32x1o+32x2e", 2, "float32"),
+])
+def test_gpu_forward_vs_oracle(in1, out, lmax_sh, dtype):
+    from scalable_e3_gnn_amd.tensor_product import SHTensorProduct
+    torch.manual_seed(0)
+    dt = getattr(torch, dtype)
+    mod = SHTensorProduct(in1, out, lmax_sh).to(dt).to("cuda:0")
+    B = 203
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, mod.in1_dim, generator=g, dtype=torch.float64)
+    y = torch.randn(B, mod.in2_dim, generator=g, dtype=torch.float64)
+    W = {c: getattr(mod, "weights_" + c).detach().double().cpu().numpy() for c in T.CLASSES if hasattr(mod, "weights_" + c)}
+    N = {c: getattr(mod, "norm_" + c).double().cpu().numpy() for c in T.CLASSES}
+    # default norms follow sqrt((2l+1)/fan_in)
+    dn = T.default_norms(in1, out, lmax_sh)
+    for c in T.CLASSES:
+        assert np.allclose(N[c], dn[c], rtol=1e-6)
+    want = T.forward(in1, out, lmax_sh, x.numpy(), y.numpy(), W, N)
+    with torch.no_grad():
+        got = mod(x.to(dt).to("cuda:0"), y.to(dt).to("cuda:0")).double().cpu().numpy()
+    err = np.abs(got - want).max() / np.abs(want).max()
+    assert err < (1e-12 if dtype == "float64" else 1e-5), err
+
+
+@pytest.mark.gpu
+def test_gpu_reduces_to_l1tp_kernel():
+    from models.segnn.l1_tensor_prod import L1TensorProduct
+    from scalable_e3_gnn_amd.tensor_product import SHTensorProduct
+    torch.manual_seed(1)
+    a = L1TensorProduct("16x0e+16x1o", "24x0e+8x1o").to("cuda:0")
+    b = SHTensorProduct("16x0e+16x1o", "24x0e+8x1o", 1).to("cuda:0")
+    with torch.no_grad():
+        b.weights_l0e.copy_(a.weights_l0e)
+        b.weights_l1o.copy_(a.weights_l1o)
+        assert torch.allclose(a.norm_l0e, b.norm_l0e) and torch.allclose(a.norm_l1o, b.norm_l1o)
+        x, y = torch.randn(500, 64, device="cuda:0"), torch.randn(500, 4, device="cuda:0")
+        assert ((a(x, y) - b(x, y)).abs().max() / a(x, y).abs().max()).item() < 1e-5
+
+
+@pytest.mark.gpu
+def test_gpu_equivariance_l2():
+    from scalable_e3_gnn_amd.tensor_product import SHTensorProduct
+    torch.manual_seed(2)
+    irreps = "4x0e+3x1o+2x2e+1x1e"
+    mod = SHTensorProduct(irreps, "3x0e+2x1o+2x2e+1x0o+1x1e+1x2o", 2).double().to("cuda:0")
+    rng = np.random.default_rng(3)
+    R = CG.random_rotation(rng)
+    B = 50
+    x = rng.normal(size=(B, mod.in1_dim))
+    rel = rng.normal(size=(B, 3))
+    def rot_feat(v, irr):
+        v = v.copy(); col = 0
+        for l, p, mul in O1.parse_blocks(irr):
+            w = 2 * l + 1
+            if l > 0:
+                D = CG.rotation_matrices(l, R)
+                v[:, col:col + w * mul] = (v[:, col:col + w * mul].reshape(-1, mul, w) @ D.T).reshape(-1, w * mul)
+            col += w * mul
+        return v
+    f = lambda xx, rr: mod(torch.tensor(xx, device="cuda:0"), torch.tensor(CG.sh_component(2, rr), device="cuda:0")).cpu().numpy()
+    with torch.no_grad():
+        o1 = f(x, rel)
+        o2 = f(rot_feat(x, irreps), rel @ R.T)
+    assert np.abs(o2 - rot_feat(o1, "3x0e+2x1o+2x2e+1x0o+1x1e+1x2o")).max() < 1e-11
