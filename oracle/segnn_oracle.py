@@ -36,6 +36,61 @@ def tp(params, prefix, in1, in2, in_irreps, out_irreps):
     return O.forward_closed_form(lay, in1, in2, W, N)
 
 
+def edge_geometry_l2(pos, rowptr, src):
+    from . import cg
+    N = len(rowptr) - 1
+    dst = np.repeat(np.arange(N), np.diff(rowptr))
+    rel = pos[src].astype(np.float64) - pos[dst].astype(np.float64)
+    d = np.sqrt((rel * rel).sum(1))
+    Y = cg.sh_component(2, rel)
+    A = np.zeros((N, 9))
+    A[:, 0] = 1.0
+    deg = np.diff(rowptr)
+    np.add.at(A[:, 1:], dst, Y[:, 1:])
+    A[deg > 0, 1:] /= deg[deg > 0, None]
+    return Y, d, A, dst
+
+
+def gate_blocks(x, ns, blocks):
+    sig = lambda t: 1.0 / (1.0 + np.exp(-t))
+    ng = sum(m for _, m in blocks)
+    out = [x[:, :ns] * sig(x[:, :ns])]
+    g0, c0 = ns, ns + ng
+    for l, m in blocks:
+        w = 2 * l + 1
+        blk = x[:, c0:c0 + m * w].reshape(len(x), m, w)
+        out.append((sig(x[:, g0:g0 + m])[:, :, None] * blk).reshape(len(x), m * w))
+        g0 += m
+        c0 += m * w
+    return np.concatenate(out, 1)
+
+
+def forward_l2(params, H, num_layers, in_irreps, out_irreps, x, pos, rowptr, src):
+    """l_max = 2 model (hidden Hx0e+Hx1o+Hx2e), every TP through tp_oracle."""
+    from . import tp_oracle as T
+    hid = f"{H}x0e+{H}x1o+{H}x2e"
+    gated = f"{H}x0e+{2 * H}x0e+{H}x1o+{H}x2e"
+    Y, d, A, dst = edge_geometry_l2(pos, rowptr, src)
+
+    def tp2(prefix, in1, in2, ii, oi):
+        W = {c: params[f"{prefix}.weights_{c}"] for c in T.CLASSES if f"{prefix}.weights_{c}" in params}
+        Nn = {c: params[f"{prefix}.norm_{c}"] for c in T.CLASSES}
+        return T.forward(ii, oi, 2, in1, in2, W, Nn)
+
+    g = lambda t: gate_blocks(t, H, [(1, H), (2, H)])
+    h = tp2("embed", x, A, in_irreps, hid)
+    for l in range(num_layers):
+        p = f"layers.{l}"
+        m = np.concatenate([h[dst], h[src], d[:, None]], 1)
+        m = g(tp2(p + ".msg1", m, Y, f"{hid}+{hid}+1x0e", gated))
+        m = g(tp2(p + ".msg2", m, Y, hid, gated))
+        a = np.zeros_like(h)
+        np.add.at(a, dst, m)
+        u = g(tp2(p + ".upd1", np.concatenate([h, a], 1), A, f"{hid}+{hid}", gated))
+        h = h + tp2(p + ".upd2", u, A, hid, hid)
+    return tp2("readout", h, A, hid, out_irreps)
+
+
 def forward(params, H, num_layers, in_irreps, out_irreps, x, pos, rowptr, src, return_all=False, exchange=None):
     """params: dict name -> np array (state_dict of scalable_e3_gnn_amd.segnn.SEGNN)."""
     hid = f"{H}x0e+{H}x1o"
@@ -106,3 +161,47 @@ def forward_torch_cpu(params, H, num_layers, in_irreps, out_irreps, x, pos, rowp
         u = gate_t(tp(p + ".upd1", torch.cat([h, a], 1), A, f"{hid}+{hid}", gated))
         h = h + tp(p + ".upd2", u, A, hid, hid)
     return tp("readout", h, A, hid, out_irreps)
+
+
+def forward_l2_torch_cpu(params, H, num_layers, in_irreps, out_irreps, x, pos, rowptr, src):
+    """fp32 torch-CPU l_max = 2 pipeline (bench.py cpu_baseline, kind "port")."""
+    import torch
+    from . import cg, tp_oracle as T
+    hid = f"{H}x0e+{H}x1o+{H}x2e"
+    gated = f"{H}x0e+{2 * H}x0e+{H}x1o+{H}x2e"
+    rowptr_t, src_t = torch.as_tensor(rowptr).long(), torch.as_tensor(src).long()
+    N = rowptr_t.numel() - 1
+    deg = rowptr_t[1:] - rowptr_t[:-1]
+    dst_t = torch.repeat_interleave(torch.arange(N), deg)
+    pos = torch.as_tensor(pos, dtype=torch.float32)
+    rel = pos[src_t] - pos[dst_t]
+    d = rel.norm(dim=1)
+    Y = torch.as_tensor(cg.sh_component(2, rel.numpy()), dtype=torch.float32)
+    A = torch.zeros(N, 9)
+    A[:, 0] = 1.0
+    A[:, 1:].index_add_(0, dst_t, Y[:, 1:])
+    A[:, 1:] /= deg.clamp_min(1)[:, None]
+    P = {k: torch.as_tensor(v, dtype=torch.float32) for k, v in params.items()}
+
+    def tp2(prefix, in1, in2, ii, oi):
+        W = {c: P[f"{prefix}.weights_{c}"] for c in T.CLASSES if f"{prefix}.weights_{c}" in P}
+        Nn = {c: P[f"{prefix}.norm_{c}"] for c in T.CLASSES}
+        return T.forward_torch_cpu(ii, oi, 2, in1, in2, W, Nn)
+
+    def g(t):
+        s, g1, g2 = t[:, :H], t[:, H:2 * H], t[:, 2 * H:3 * H]
+        v1 = t[:, 3 * H:6 * H].reshape(-1, H, 3)
+        v2 = t[:, 6 * H:].reshape(-1, H, 5)
+        return torch.cat([torch.nn.functional.silu(s), (torch.sigmoid(g1)[:, :, None] * v1).reshape(-1, 3 * H),
+                          (torch.sigmoid(g2)[:, :, None] * v2).reshape(-1, 5 * H)], 1)
+
+    h = tp2("embed", torch.as_tensor(x, dtype=torch.float32), A, in_irreps, hid)
+    for l in range(num_layers):
+        p = f"layers.{l}"
+        m = torch.cat([h[dst_t], h[src_t], d[:, None]], 1)
+        m = g(tp2(p + ".msg1", m, Y, f"{hid}+{hid}+1x0e", gated))
+        m = g(tp2(p + ".msg2", m, Y, hid, gated))
+        a = torch.zeros_like(h).index_add_(0, dst_t, m)
+        u = g(tp2(p + ".upd1", torch.cat([h, a], 1), A, f"{hid}+{hid}", gated))
+        h = h + tp2(p + ".upd2", u, A, hid, hid)
+    return tp2("readout", h, A, hid, out_irreps)

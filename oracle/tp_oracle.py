@@ -76,11 +76,41 @@ def forward(in1_irreps, out_irreps, lmax_sh, in1, in2, W, norms):
         for c1, l1, l2 in paths(c3, n_in, lmax_sh):
             x = in1[:, ic[c1]]                                    # [B, n, 2l1+1]
             y = in2[:, l2 * l2:(l2 + 1) * (l2 + 1)]               # [B, 2l2+1]
-            feats.append(np.einsum("bkm,bn,mnq->bkq", x, y, CG.cg(l1, l2, l3)))
+            z = np.einsum("bn,mnq->bmq", y, CG.cg(l1, l2, l3))   # [B, 2l1+1, 2l3+1]
+            feats.append(np.matmul(x, z))
         if not feats:
             continue
         F = np.concatenate(feats, 1)                              # [B, K, 2l3+1]
-        o = np.einsum("bkq,kw->bwq", F, np.asarray(W[name], np.float64))
+        o = np.einsum("bkq,kw->bwq", F, np.asarray(W[name], np.float64), optimize=True)
         o = o.reshape(B, -1) * np.asarray(norms[name], np.float64)
         out[:, oc[c3].reshape(-1)] = o
+    return out
+
+
+def forward_torch_cpu(in1_irreps, out_irreps, lmax_sh, in1, in2, W, norms, _cache={}):
+    """fp32 torch-CPU port of the same contraction with the reference's op *pattern* (class gather ->
+    per-path feature -> cat -> matmul -> column scatter -> norm); bench.py cpu_baseline for l_max = 2."""
+    import torch
+    key = (str(in1_irreps), str(out_irreps), lmax_sh)
+    if key not in _cache:
+        ib, ob = parse_blocks(in1_irreps), parse_blocks(out_irreps)
+        ic, oc = class_columns(ib), class_columns(ob)
+        _cache[key] = (ic, oc, {c: len(ic[c]) for c in range(6)}, sum((2 * l + 1) * m for l, _, m in ob))
+    ic, oc, n_in, dout = _cache[key]
+    B = in1.shape[0]
+    out = torch.empty((B, dout), dtype=in1.dtype)
+    for c3, name in enumerate(CLASSES):
+        if len(oc[c3]) == 0:
+            continue
+        l3 = c3 >> 1
+        feats = []
+        for c1, l1, l2 in paths(c3, n_in, lmax_sh):
+            x = in1[:, torch.as_tensor(ic[c1].reshape(-1))].reshape(B, -1, 2 * l1 + 1)
+            y = in2[:, l2 * l2:(l2 + 1) * (l2 + 1)]
+            C = torch.as_tensor(CG.cg(l1, l2, l3), dtype=in1.dtype)
+            z = torch.einsum("bn,mnq->bmq", y, C)
+            feats.append(torch.bmm(x, z))
+        F = torch.cat(feats, 1)
+        o = torch.tensordot(F, W[name], ([1], [0])).transpose(-1, -2).reshape(B, -1)
+        out[:, torch.as_tensor(oc[c3].reshape(-1))] = o * norms[name]
     return out

@@ -1,7 +1,8 @@
 """SEGNN forward built on ``L1TensorProduct`` (builder-defined architecture: the reference mount has
 only the tensor product; this file is the repo's written contract for the rest).
 
-Steerable E(3) message passing with l <= 1 (``Hx0e+Hx1o`` hidden features), for a radius graph given
+Steerable E(3) message passing with ``l_max`` 1 (``Hx0e+Hx1o`` hidden features, every TP is the
+reference operator) or 2 (``Hx0e+Hx1o+Hx2e``, TPs = ``SHTensorProduct``), for a radius graph given
 as CSR-by-dst in Morton order (``radius_graph``):
 
     Y_e = SH_{l<=1}(x_src - x_dst)  (component norm.),  d_e = |x_src - x_dst|,  A_i = [1, mean_e Y1_e]
@@ -25,39 +26,56 @@ from . import ops
 from .irreps import Irreps
 from .l1_tensor_prod import L1TensorProduct
 from .radius_graph import RadiusGraph
+from .tensor_product import SHTensorProduct
+
+
+def _hidden_irreps(H: int, lmax: int):
+    hid = Irreps(f"{H}x0e+{H}x1o" + (f"+{H}x2e" if lmax == 2 else ""))
+    gated = Irreps(f"{H}x0e+{lmax * H}x0e+{H}x1o" + (f"+{H}x2e" if lmax == 2 else ""))
+    return hid, gated
+
+
+def _make_tp(in_irreps, out_irreps, lmax: int):
+    """l_max = 1: the reference operator (pinned).  l_max = 2: its builder-defined generalisation."""
+    if lmax == 1:
+        return L1TensorProduct(in_irreps, out_irreps)
+    return SHTensorProduct(in_irreps, out_irreps, lmax_sh=2)
 
 
 class SEGNNLayer(nn.Module):
-    def __init__(self, H: int):
+    def __init__(self, H: int, lmax: int = 1):
         super().__init__()
-        hid = Irreps(f"{H}x0e+{H}x1o")
-        gated = Irreps(f"{H}x0e+{H}x0e+{H}x1o")
-        self.H = H
-        self.msg1 = L1TensorProduct(hid + hid + Irreps("1x0e"), gated)
-        self.msg2 = L1TensorProduct(hid, gated)
-        self.upd1 = L1TensorProduct(hid + hid, gated)
-        self.upd2 = L1TensorProduct(hid, hid)
+        hid, gated = _hidden_irreps(H, lmax)
+        self.H, self.lmax = H, lmax
+        self.msg1 = _make_tp(hid + hid + Irreps("1x0e"), gated, lmax)
+        self.msg2 = _make_tp(hid, gated, lmax)
+        self.upd1 = _make_tp(hid + hid, gated, lmax)
+        self.upd2 = _make_tp(hid, hid, lmax)
+
+    def _gate(self, t):
+        H = self.H
+        return ops.gate(t, H, H) if self.lmax == 1 else ops.gate_blocks(t, H, [(1, H), (2, H)])
 
     def forward(self, h, g: RadiusGraph, Y, d, A):
-        H = self.H
         m = ops.gather_concat(h, g, d)
-        m = ops.gate(self.msg1(m, Y), H, H)
-        m = ops.gate(self.msg2(m, Y), H, H)
+        m = self._gate(self.msg1(m, Y))
+        m = self._gate(self.msg2(m, Y))
         a = ops.segment_sum(m, g)
-        u = ops.gate(self.upd1(torch.cat([h, a], 1), A), H, H)
+        u = self._gate(self.upd1(torch.cat([h, a], 1), A))
         u = self.upd2(u, A)
         return h + u
 
 
 class SEGNN(nn.Module):
-    def __init__(self, in_irreps="1x0e+1x1o", hidden: int = 32, out_irreps="1x1o", num_layers: int = 4):
+    def __init__(self, in_irreps="1x0e+1x1o", hidden: int = 32, out_irreps="1x1o", num_layers: int = 4, lmax: int = 1):
         super().__init__()
-        self.hidden = hidden
-        hid = Irreps(f"{hidden}x0e+{hidden}x1o")
+        assert lmax in (1, 2)
+        self.hidden, self.lmax = hidden, lmax
+        hid, _ = _hidden_irreps(hidden, lmax)
         self.in_irreps, self.out_irreps = Irreps(in_irreps), Irreps(out_irreps)
-        self.embed = L1TensorProduct(self.in_irreps, hid)
-        self.layers = nn.ModuleList([SEGNNLayer(hidden) for _ in range(num_layers)])
-        self.readout = L1TensorProduct(hid, self.out_irreps)
+        self.embed = _make_tp(self.in_irreps, hid, lmax)
+        self.layers = nn.ModuleList([SEGNNLayer(hidden, lmax) for _ in range(num_layers)])
+        self.readout = _make_tp(hid, self.out_irreps, lmax)
 
     def forward(self, x: torch.Tensor, g: RadiusGraph, geometry=None, halo=None) -> torch.Tensor:
         """x [N, in_dim] node features in the graph's (Morton) order -> [N, out_dim] in the same order.
@@ -65,7 +83,7 @@ class SEGNN(nn.Module):
         ``halo`` (``sharding.SlabHalo``): when the cloud is spatially sharded, ghost rows of ``h`` are
         refreshed from their owners before every message-passing layer; only owned rows of the result
         are meaningful."""
-        Y, d, A = geometry if geometry is not None else ops.edge_geometry(g)
+        Y, d, A = geometry if geometry is not None else ops.edge_geometry(g, lmax=self.lmax)
         h = self.embed(x, A)
         for layer in self.layers:
             if halo is not None:

@@ -86,3 +86,25 @@ def test_segnn_equivariance():
     # a handful of pairs sit within fp32 rounding of the cutoff and may flip; compare the bulk
     err = ((o2 - o @ R.T).abs().max(1).values / o.abs().max())
     assert (err < 1e-3).float().mean() > 0.99 and err.median() < 1e-5
+
+
+def test_segnn_lmax2_forward_vs_oracle():
+    """l_max = 2 (the BASELINE headline configuration's operator set) at a size the oracle finishes in seconds."""
+    N, H, L = 800, 8, 2
+    torch.manual_seed(5)
+    pos = torch.rand(N, 3, generator=torch.Generator().manual_seed(5))
+    r = float((3 * 12.0 / (4 * np.pi * N)) ** (1 / 3))
+    model = SEGNN("1x0e+1x1o", H, "1x1o", L, lmax=2).to(DEV)
+    g = radius_graph(pos.to(DEV), r, [0, 0, 0], [1, 1, 1])
+    x = torch.randn(N, 4, generator=torch.Generator().manual_seed(6))
+    xs = x[g.perm.cpu().long()]
+    with torch.no_grad():
+        out = model(xs.to(DEV), g)
+    Y, d, A = ops.edge_geometry(g, lmax=2)
+    perm = g.perm.cpu().numpy()
+    Yo, do, Ao, _ = S.edge_geometry_l2(pos.numpy()[perm], g.rowptr.cpu().numpy(), g.src.cpu().numpy())
+    assert rel(Y, Yo) < 1e-5 and rel(A, Ao) < 1e-5
+    params = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    want = S.forward_l2(params, H, L, "1x0e+1x1o", "1x1o", xs.double().numpy(), pos.numpy()[perm],
+                        g.rowptr.cpu().numpy(), g.src.cpu().numpy())
+    assert rel(out, want) < 1e-4, rel(out, want)
