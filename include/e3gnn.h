@@ -190,6 +190,14 @@ int e3_segment_sum(const float* msg, int64_t ld_msg, const int32_t* rowptr, int6
  * With l <= 1 irreps, lmax_sh = 1 and the same weights/norms, e3_tp_forward == e3_l1tp_forward.
  * ================================================================================================= */
 typedef struct e3_tp_plan e3_tp_plan;
+/* one column segment of in1 for the fused entry point: rows are base[row_index[b] * ld + c] (row_index NULL = b) */
+typedef struct e3_tp_segment {
+  const void* base;
+  int64_t ld;
+  const int32_t* row_index;
+  int32_t ncols;
+  int32_t reserved;
+} e3_tp_segment;
 int e3_tp_plan_create(const int32_t* in1_blocks, int n_in1, int lmax_sh,
                       const int32_t* out_blocks, int n_out, e3_tp_plan** plan);
 int e3_tp_plan_destroy(e3_tp_plan* plan);
@@ -205,6 +213,19 @@ int e3_tp_pack_weights(const e3_tp_plan* plan, const void* const weights[6], con
 /* dtype E3_F32 or E3_F64; ld_in2 == 0 broadcasts row 0 of in2 */
 int e3_tp_forward(const e3_tp_plan* plan, const void* in1, int64_t ld_in1, const void* in2, int64_t ld_in2,
                   const void* packed, void* out, int64_t ld_out, int64_t B, int dtype, void* stream);
+/*
+ * Fused message-function form (fp32 MFMA kernel, natural-parity irreps 0e/1o/2e only):
+ *   in1[b] = [ seg0.base[idx0[b]] | seg1.base[idx1[b]] | ... ]   (the gather and the concat never reach HBM;
+ *            segment boundaries must fall on irreps-block boundaries, at most 4 segments)
+ *   gate != 0: out irreps must be [32x0e | 32x0e per gated block | 32x1o | 32x2e]; the kernel writes
+ *              [silu(s) | sigmoid(g1) v1 | sigmoid(g2) v2] (width 32 + 96 (+160)) instead of the raw TP output.
+ * Returns E3_ERR_UNSUPPORTED when the plan / shape has no MFMA instantiation (callers then use
+ * e3_gather_concat + e3_tp_forward + e3_gate_blocks).  e3_tp_fused_supported() answers that up front.
+ */
+int e3_tp_forward_fused(const e3_tp_plan* plan, const e3_tp_segment* segs, int nseg,
+                        const void* in2, int64_t ld_in2, const void* packed, void* out, int64_t ld_out,
+                        int64_t B, int dtype, int gate, void* stream);
+int e3_tp_fused_supported(const e3_tp_plan* plan, int gate);
 /* SH / geometry for lmax 2: edge_y [E,9], node_a [N,9] (same definitions as e3_edge_geometry, Y2 = sqrt5 b(r^)) */
 int e3_edge_geometry_l2(const float* pos4, const int32_t* rowptr, const int32_t* src, int64_t N,
                         float* edge_y, float* edge_d, float* node_a, void* stream);

@@ -3,12 +3,12 @@
 // with W first (T[m1] = sum_k W[k,w] x[k,m1]) and applies the coupling tensor and Y afterwards.
 #include "e3_common.h"
 #include "cg_tables.h"
+#include "e3_tp_internal.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace e3 {
-
-struct TpPath { int c1, l1, l2, wrow; };
 
 struct TpDev {
   int D1, Dout, Dy, lmax_sh;
@@ -28,6 +28,7 @@ struct e3_tp_plan {
   std::vector<e3::TpPath> h_paths;
   int32_t* d_tables = nullptr;
   e3::TpPath* d_paths = nullptr;
+  e3::TpFast fast;
   std::mutex mu;
 };
 
@@ -151,6 +152,8 @@ static int tp_ensure_device(const e3_tp_plan* cplan) {
   P->dev.cpos = d;
   P->dev.ocol = d + P->dev.D1;
   P->dev.paths = P->d_paths;
+  int st = fast_upload(&P->fast);
+  if (st != E3_OK) return st;
   P->d_tables = d;
   return E3_OK;
 }
@@ -255,6 +258,14 @@ int e3_tp_plan_create(const int32_t* in1_blocks, int n_in1, int lmax_sh, const i
   }
   d.normcol_off = wpos;
   d.packed_elems = wpos + d.Dout;
+  {
+    std::vector<std::array<int, 4>> blocks;
+    for (auto& b : bi) blocks.push_back({b.l, b.p, b.mul, b.col});
+    std::vector<TpPath> by_class[6];
+    for (int c3 = 0; c3 < 6; ++c3)
+      for (int i = 0; i < d.npath[c3]; ++i) by_class[c3].push_back(P->h_paths[d.poff[c3] + i]);
+    fast_plan_init(&P->fast, d.n, d.M, lmax_sh, d.Dout, d.Dy, blocks, by_class, d.ocol_off);
+  }
   *plan_out = P;
   return E3_OK;
 }
@@ -263,6 +274,7 @@ int e3_tp_plan_destroy(e3_tp_plan* P) {
   if (!P) return E3_OK;
   if (P->d_tables) (void)hipFree(P->d_tables);
   if (P->d_paths) (void)hipFree(P->d_paths);
+  fast_free(&P->fast);
   delete P;
   return E3_OK;
 }
@@ -282,8 +294,11 @@ int e3_tp_norm_len(const e3_tp_plan* p, int cls) {
 }
 int64_t e3_tp_packed_bytes(const e3_tp_plan* p, int dtype) {
   if (!p || (dtype != E3_F32 && dtype != E3_F64)) return -1;
-  return (p->dev.packed_elems + 64) * (dtype == E3_F64 ? 8 : 4);
+  int64_t b = ((p->dev.packed_elems + 64) * (dtype == E3_F64 ? 8 : 4) + 255) / 256 * 256;
+  if (dtype == E3_F32) b += fast_packed_bytes(&p->fast);
+  return b;
 }
+static inline int64_t fast_section_offset(const e3_tp_plan* p) { return ((p->dev.packed_elems + 64) * 4 + 255) / 256 * 256; }
 
 int e3_tp_pack_weights(const e3_tp_plan* plan, const void* const w[6], const void* const n[6], int dtype, void* packed,
                        void* stream) {
@@ -307,6 +322,8 @@ int e3_tp_pack_weights(const e3_tp_plan* plan, const void* const w[6], const voi
                        (const double*)nn[0], (const double*)nn[1], (const double*)nn[2], (const double*)nn[3],
                        (const double*)nn[4], (const double*)nn[5], (double*)packed, plan->dev);
   E3_HIP_CHECK(hipGetLastError());
+  if (dtype == E3_F32 && plan->fast.usable)
+    return fast_pack(&plan->fast, w, nn, (char*)packed + fast_section_offset(plan), plan->dev.ocol, s);
   return E3_OK;
 }
 
@@ -319,8 +336,35 @@ int e3_tp_forward(const e3_tp_plan* plan, const void* in1, int64_t ld1, const vo
   int st = tp_ensure_device(plan);
   if (st != E3_OK) return st;
   hipStream_t s = (hipStream_t)stream;
+  static const bool no_fast = getenv("E3_TP_GENERIC") != nullptr;
+  if (dtype == E3_F32 && plan->fast.usable && ld2 != 0 && !no_fast) {
+    e3_tp_segment seg = {in1, ld1, nullptr, plan->dev.D1, 0};
+    return fast_forward(&plan->fast, &seg, 1, plan->dev.D1, in2, ld2, (const char*)packed + fast_section_offset(plan),
+                        out, ldo, B, 0, plan->dev.ocol, s);
+  }
   return dtype == E3_F32 ? tp_launch_fwd<float>(plan, in1, ld1, in2, ld2, packed, out, ldo, B, s)
                          : tp_launch_fwd<double>(plan, in1, ld1, in2, ld2, packed, out, ldo, B, s);
+}
+
+int e3_tp_forward_fused(const e3_tp_plan* plan, const e3_tp_segment* segs, int nseg, const void* in2, int64_t ld2,
+                        const void* packed, void* out, int64_t ldo, int64_t B, int dtype, int gate, void* stream) {
+  if (!plan || !segs || B < 0) return E3_ERR_INVALID_ARG;
+  if (dtype != E3_F32 || !plan->fast.usable || ld2 == 0) return E3_ERR_UNSUPPORTED;
+  if (B == 0) return E3_OK;
+  if (!in2 || !packed || !out || ld2 < plan->dev.Dy) return E3_ERR_INVALID_ARG;
+  int st = tp_ensure_device(plan);
+  if (st != E3_OK) return st;
+  return fast_forward(&plan->fast, segs, nseg, plan->dev.D1, in2, ld2, (const char*)packed + fast_section_offset(plan),
+                      out, ldo, B, gate, plan->dev.ocol, (hipStream_t)stream);
+}
+
+int e3_tp_fused_supported(const e3_tp_plan* plan, int gate) {
+  if (!plan || !plan->fast.usable) return 0;
+  if (!gate) return 1;
+  const FDev& d = plan->fast.dev;
+  const int nb = (d.NT[1] > 0) + (d.NT[2] > 0);
+  return (d.NT[0] == 1 + nb && d.M[0] == 32 * (1 + nb) && (!d.NT[1] || d.M[1] == 32) && (!d.NT[2] || d.M[2] == 32) &&
+          d.NT[1] <= 1 && d.NT[2] <= 1) ? 1 : 0;
 }
 
 }  // extern "C"

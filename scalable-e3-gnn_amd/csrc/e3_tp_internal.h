@@ -1,0 +1,45 @@
+// Internal declarations shared by e3_tp.hip (plan, generic kernel, C ABI) and e3_tp_mfma.hip (MFMA kernel).
+#pragma once
+#include "e3_common.h"
+
+#include <array>
+#include <vector>
+
+namespace e3 {
+
+struct TpPath { int c1, l1, l2, wrow; };
+
+struct FChunk {  // one piece (<= 32 channels) of an in1 irreps block, natural parity class of degree l1
+  int col, count, l1;
+  int wrow[3][3];  // [l2][l3]: first packed weight row in class l3's matrix, -1 = no coupling
+};
+struct FDev {
+  int Dout, Dy, nchunks, nwaves, nbuf, w_in_lds, wtotal, ntab, lsh;
+  int M[3], NT[3], Mpad[3], woff[3], ooff[3];  // per output degree l3 (classes 0e, 1o, 2e)
+};
+struct FPack { int l3, orig_row, count, wrow; };
+
+struct TpFast {
+  FDev dev;
+  std::vector<FChunk> h_chunks;
+  std::vector<FPack> h_pack;
+  FChunk* d_chunks = nullptr;
+  FPack* d_pack = nullptr;
+  FDev* d_dev = nullptr;
+  bool usable = false;
+  size_t lds_bytes = 0;
+};
+
+int fast_plan_init(TpFast* F, const int n[6], const int M[6], int lmax_sh, int Dout, int Dy,
+                   const std::vector<std::array<int, 4>>& in_blocks, const std::vector<TpPath>* paths_by_class,
+                   const int ocol_off[6]);
+int fast_upload(TpFast* F);
+void fast_free(TpFast* F);
+int64_t fast_packed_bytes(const TpFast* F);
+int fast_pack(const TpFast* F, const void* const w[6], const void* const n[6], void* packed, const int32_t* ocol_tab,
+              hipStream_t s);
+int fast_forward(const TpFast* F, const e3_tp_segment* segs, int nseg, int D1, const void* in2, int64_t ld2,
+                 const void* packed, void* out, int64_t ldo, int64_t B, int gate, const int32_t* ocol_tab,
+                 hipStream_t s);
+
+}  // namespace e3

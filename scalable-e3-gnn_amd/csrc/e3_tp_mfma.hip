@@ -1,0 +1,629 @@
+// fp32 MFMA kernel for the general SH tensor product (l <= 2, natural-parity classes 0e / 1o / 2e),
+// with optional fused row gather (in1 = concatenation of row-indexed segments) and fused gate.
+//
+// Structure ("K-outer, all outputs resident"): one wave owns a tile of 32 rows and keeps EVERY output
+// accumulator of those rows in registers (NT0 scalar tiles + 3*NT1 + 5*NT2 accumulators of 16 VGPRs).  It
+// then walks the input irreps blocks ("chunks" of <= 32 channels): each chunk is staged once into a small
+// LDS buffer by LDS-DMA (gathered per row when a segment carries a row index) and contracted on the
+// matrix core (v_mfma_f32_32x32x2_f32) into every output class it couples to:
+//     A operand = packed weights W'[k][32 t + (lane&31)]           (LDS when they fit, else L2)
+//     B operand = per-row feature  sum_m1 z[m1][m3] x[k][m1]        z = sum_m2 C[m1][m2][m3] Y[m2]  (per lane)
+// or, when 2 l1 + 1 < 2 l3 + 1, the raw x[k][m1] into temporaries that are folded with z afterwards.
+// So every input element is read from HBM/L2 once per tile and every output is written once; the gather,
+// the concat and the gate of the SEGNN message function never materialise in HBM.
+#include "e3_common.h"
+#include "cg_tables.h"
+#include "e3_tp_internal.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <type_traits>
+#include <vector>
+
+namespace e3 {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_void_t;
+
+constexpr int kFastLds = 160 * 1024;
+constexpr int kChunkFloats = 32 * 161;  // 32 rows x (32 ch x 5 comps | 1)
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ void wave_sync_lds() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// contract one staged chunk (class l1) into the accumulators of one output tile of class l3 through SH degree l2
+template <int L1, int L2, int L3>
+__device__ __forceinline__ void run_steps(const float* __restrict__ xr, const int count, const float* __restrict__ wp,
+                                          const int Mpad, const int half, const float (&y)[9],
+                                          f32x16 (&acc)[2 * L3 + 1]) {
+  constexpr int D1 = 2 * L1 + 1, D2 = 2 * L2 + 1, D3 = 2 * L3 + 1;
+  constexpr bool MIX = D1 < D3;
+  constexpr int U = (D1 == 1) ? 4 : 2;
+  using C = CG<L1, L2, L3>;
+  __builtin_amdgcn_sched_barrier(0);  // keep the scheduler from interleaving independent path loops
+  // z is tile-invariant: without this the compiler hoists the z matrices of ALL paths out of the chunk loop and keeps
+  // ~150 VGPRs of them live (spills).  Making Y opaque here pins the (cheap) recomputation next to its use.
+  float yl[D2];
+#pragma unroll
+  for (int b = 0; b < D2; ++b) {
+    yl[b] = y[L2 * L2 + b];
+    asm volatile("" : "+v"(yl[b]));
+  }
+  float z[D1][D3];
+#pragma unroll
+  for (int a = 0; a < D1; ++a)
+#pragma unroll
+    for (int c = 0; c < D3; ++c) {
+      float s = 0.f;
+#pragma unroll
+      for (int b = 0; b < D2; ++b)
+        if (C::v[a][b][c] != 0.0) s += (float)C::v[a][b][c] * yl[b];
+      z[a][c] = s;
+    }
+  f32x16 T[MIX ? D1 : 1];
+  if (MIX) {
+#pragma unroll
+    for (int a = 0; a < D1; ++a) T[a] = f32x16{0};
+  }
+  const float* xp = xr + half * D1;
+  auto load = [&](int p, float& a, float (&x)[D1]) {
+    a = wp[(2 * p) * Mpad];
+#pragma unroll
+    for (int m = 0; m < D1; ++m) x[m] = xp[2 * p * D1 + m];
+  };
+  auto step = [&](float a, const float (&x)[D1], bool valid) {
+    if (MIX) {
+#pragma unroll
+      for (int m = 0; m < D1; ++m) T[m] = mfma32(a, valid ? x[m] : 0.f, T[m]);
+    } else {
+#pragma unroll
+      for (int c = 0; c < D3; ++c) {
+        float b = 0.f;
+#pragma unroll
+        for (int m = 0; m < D1; ++m) {
+          bool nz = false;
+#pragma unroll
+          for (int q = 0; q < D2; ++q) nz |= (C::v[m][q][c] != 0.0);
+          if (nz) b += z[m][c] * x[m];
+        }
+        acc[c] = mfma32(a, valid ? b : 0.f, acc[c]);
+      }
+    }
+  };
+  const int npair = count >> 1;
+  const int ngrp = npair / U;
+  if (ngrp > 0) {
+    float a[U], x[U][D1];
+#pragma unroll
+    for (int u = 0; u < U; ++u) load(u, a[u], x[u]);
+    for (int g = 1; g < ngrp; ++g) {
+      float an[U], xn[U][D1];
+#pragma unroll
+      for (int u = 0; u < U; ++u) load(g * U + u, an[u], xn[u]);
+#pragma unroll
+      for (int u = 0; u < U; ++u) step(a[u], x[u], true);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        a[u] = an[u];
+#pragma unroll
+        for (int m = 0; m < D1; ++m) x[u][m] = xn[u][m];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) step(a[u], x[u], true);
+  }
+  for (int p = ngrp * U; p < npair; ++p) {
+    float a, x[D1];
+    load(p, a, x);
+    step(a, x, true);
+  }
+  if (count & 1) {
+    float a, x[D1];
+    load(npair, a, x);
+    step(a, x, half == 0);
+  }
+  if (MIX) {
+#pragma unroll
+    for (int c = 0; c < D3; ++c)
+#pragma unroll
+      for (int a = 0; a < D1; ++a) {
+        bool nz = false;
+#pragma unroll
+        for (int q = 0; q < D2; ++q) nz |= (C::v[a][q][c] != 0.0);
+        if (nz) acc[c] += T[a] * z[a][c];
+      }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+struct SegArgs {
+  const float* base[4];
+  int64_t ld[4];
+  const int32_t* index[4];
+  int col0[5];  // first in1 column of each segment; col0[nseg] = D1
+  int nseg;
+};
+
+__device__ __forceinline__ float sigmoid_(float v) { return 1.0f / (1.0f + __expf(-v)); }
+
+// LSH = SH degree of in2; NT* = number of 32-channel output tiles per degree; L1S... = degrees of the input
+// chunks in order (compile-time so that the chunk walk is straight-line code: no control-flow merges of the
+// 16-register accumulator tuples, which otherwise explode the register allocation).
+template <int LSH, int NT0, int NT1, int NT2, bool WLDS, bool GATE, int... L1S>
+__global__ __launch_bounds__(256) void tp_fwd_mfma_kernel(SegArgs segs, const float* __restrict__ in2, int64_t ld2,
+                                                          const float* __restrict__ packed, float* __restrict__ out,
+                                                          int64_t ldo, int64_t B, const FDev* __restrict__ dp,
+                                                          const FChunk* __restrict__ chunks,
+                                                          const int32_t* __restrict__ ocol_tab) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  float* lds = reinterpret_cast<float*>(smem_raw);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, half = lane >> 5;
+  const int Dout = dp->Dout, Dy = dp->Dy, wtotal = dp->wtotal, nwaves = dp->nwaves, nchunks = dp->nchunks,
+            nbuf = dp->nbuf;
+  int cM[3], cMpad[3], cWoff[3], cOoff[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { cM[c] = dp->M[c]; cMpad[c] = dp->Mpad[c]; cWoff[c] = dp->woff[c]; cOoff[c] = dp->ooff[c]; }
+  const int ntab = dp->ntab;
+
+  float* wl = lds;
+  float* nrm = lds + (WLDS ? wtotal : 0);
+  int* ocl = reinterpret_cast<int*>(nrm + ((Dout + 15) & ~15));
+  float* wbase_lds = reinterpret_cast<float*>(ocl + ((ntab + 15) & ~15));
+  const int per_wave = nbuf * kChunkFloats + 320;
+  float* cbuf = wbase_lds + (size_t)wave * per_wave;
+  float* ybuf = cbuf + nbuf * kChunkFloats;
+  if (WLDS)
+    for (int i = tid; i < wtotal; i += blockDim.x) wl[i] = packed[i];
+  for (int i = tid; i < Dout; i += blockDim.x) nrm[i] = packed[wtotal + i];
+  for (int i = tid; i < ntab; i += blockDim.x) ocl[i] = ocol_tab[i];
+  __syncthreads();
+  const float* wsrc = WLDS ? wl : packed;
+
+  const int64_t ntiles = (B + 31) / 32;
+  const int64_t tstride = (int64_t)gridDim.x * nwaves;
+
+  for (int64_t tile = (int64_t)blockIdx.x * nwaves + wave; tile < ntiles; tile += tstride) {
+    const int64_t row0 = tile * 32;
+    const int nrows = (int)((B - row0) < 32 ? (B - row0) : 32);
+
+    // stage one chunk of 32 rows (LDS-DMA; per-row gather through the segment's row index)
+    auto stage = [&](int ci, float* dst) {
+      const FChunk ch = chunks[ci];
+      int s = 0;
+      while (s + 1 < segs.nseg && ch.col >= segs.col0[s + 1]) ++s;
+      const float* base = segs.base[s];
+      const int64_t ld = segs.ld[s];
+      const int32_t* idx = segs.index[s];
+      const int segcol = ch.col - segs.col0[s];
+      const int cw = ch.count * (2 * ch.l1 + 1);
+      const int stride = cw | 1;
+      int64_t myrow = row0 + j;
+      if (idx && j < nrows) myrow = idx[row0 + j];
+      const int mr = (int)myrow;  // row ids fit int32 (N, E < 2^31)
+      if (cw == 1) {
+        if (lane < nrows)
+          __builtin_amdgcn_global_load_lds((glb_void_t*)(base + (int64_t)mr * ld + segcol), (lds_void_t*)dst, 4, 0, 0);
+        else if (lane < 32)
+          dst[lane] = 0.f;
+        return;
+      }
+      const int full = cw & ~63;
+      float* drow = dst;
+      for (int r = 0; r < 32; ++r) {
+        if (r < nrows) {
+          const int rr = __builtin_amdgcn_readlane(mr, r);
+          const float* srow = base + (int64_t)rr * ld + segcol + lane;
+          for (int dc = 0; dc < full; dc += 64)
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(srow + dc), (lds_void_t*)(drow + dc), 4, 0, 0);
+          if (full + lane < cw)
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(srow + full), (lds_void_t*)(drow + full), 4, 0, 0);
+        } else {
+          for (int dc = lane; dc < cw; dc += 64) drow[dc] = 0.f;
+        }
+        drow += stride;
+      }
+    };
+
+    // Y tile [32][Dy] (lane e of piece h fetches element h*64+e of the flattened tile)
+    for (int h = 0; h * 64 < 32 * Dy; ++h) {
+      const int e = h * 64 + lane;
+      const int yr = e / Dy, yc = e - yr * Dy;
+      if (e < 32 * Dy) {
+        if (yr < nrows)
+          __builtin_amdgcn_global_load_lds((glb_void_t*)(in2 + (row0 + yr) * ld2 + yc), (lds_void_t*)(ybuf + h * 64), 4,
+                                           0, 0);
+        else
+          ybuf[e] = 0.f;
+      }
+    }
+    stage(0, cbuf);
+
+    f32x16 a0[NT0 > 0 ? NT0 : 1][1], a1[NT1 > 0 ? NT1 : 1][3], a2[NT2 > 0 ? NT2 : 1][5];
+#pragma unroll
+    for (int t = 0; t < (NT0 > 0 ? NT0 : 1); ++t) a0[t][0] = f32x16{0};
+#pragma unroll
+    for (int t = 0; t < (NT1 > 0 ? NT1 : 1); ++t)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) a1[t][c] = f32x16{0};
+#pragma unroll
+    for (int t = 0; t < (NT2 > 0 ? NT2 : 1); ++t)
+#pragma unroll
+      for (int c = 0; c < 5; ++c) a2[t][c] = f32x16{0};
+
+    float y[9];
+    int cur = 0;
+    int ci = 0;
+    auto process = [&](auto l1tag) {
+      constexpr int L1 = decltype(l1tag)::value;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      wave_sync_lds();
+      if (ci == 0) {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) y[q] = (q < Dy) ? ybuf[j * Dy + q] : 0.f;
+      }
+      const float* xt = cbuf + cur * kChunkFloats;
+      if (nbuf == 2 && ci + 1 < nchunks) stage(ci + 1, cbuf + (cur ^ 1) * kChunkFloats);
+      const FChunk ch = chunks[ci];
+      const int cw = ch.count * (2 * L1 + 1);
+      const float* xr = xt + j * (cw | 1);
+#define E3_RUN(L2v, L3v, ACC, NTv)                                                                             \
+  if constexpr (NTv > 0 && L2v <= LSH && CG<L1, L2v, L3v>::valid && ((L1 + L2v + L3v) % 2 == 0)) {             \
+    _Pragma("unroll") for (int t = 0; t < NTv; ++t) {                                                          \
+      const float* wp = wsrc + cWoff[L3v] + (size_t)(ch.wrow[L2v][L3v] + half) * cMpad[L3v] + t * 32 + j;     \
+      run_steps<L1, L2v, L3v>(xr, ch.count, wp, cMpad[L3v], half, y, ACC);                                     \
+    }                                                                                                          \
+  }
+      E3_RUN(0, 0, a0[t], NT0) E3_RUN(1, 0, a0[t], NT0) E3_RUN(2, 0, a0[t], NT0)
+      E3_RUN(0, 1, a1[t], NT1) E3_RUN(1, 1, a1[t], NT1) E3_RUN(2, 1, a1[t], NT1)
+      E3_RUN(0, 2, a2[t], NT2) E3_RUN(1, 2, a2[t], NT2) E3_RUN(2, 2, a2[t], NT2)
+#undef E3_RUN
+      if (nbuf == 1) {
+        wave_sync_lds();
+        if (ci + 1 < nchunks) stage(ci + 1, cbuf);
+      } else {
+        cur ^= 1;
+      }
+      ++ci;
+    };
+    (process(std::integral_constant<int, L1S>{}), ...);
+
+    // ---- epilogue: norm (+ gate), transpose through LDS, coalesced stores ----
+    wave_sync_lds();
+    float* ot = cbuf;  // every input chunk is consumed: the chunk buffer becomes the out tile
+    float* const obase = out + row0 * ldo;
+    const uint32_t ldo32 = (uint32_t)ldo;
+    auto chan_of = [&](int r) { return 8 * (r >> 2) + 4 * half + (r & 3); };
+    if (GATE) {
+      // out irreps = [32 scalars | 32 gates per gated block | 32x1o | 32x2e]: a0[0] scalars, a0[1..] gates
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int chl = chan_of(r);
+        const float s = a0[0][0][r] * nrm[ocl[cOoff[0] + chl]];
+        ot[j * 33 + chl] = s * sigmoid_(s);
+      }
+      wave_sync_lds();
+      {
+        const int lc = lane & 31, rs = lane >> 5;
+        uint32_t off = (uint32_t)lc + rs * ldo32;
+        const float* src = ot + rs * 33 + lc;
+        for (int r = rs; r < nrows; r += 2) { obase[off] = *src; off += 2 * ldo32; src += 2 * 33; }
+      }
+      wave_sync_lds();
+      int ocol = 32;
+      if (NT1 > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int chl = chan_of(r);
+          const float g = sigmoid_(a0[NT0 > 1 ? 1 : 0][0][r] * nrm[ocl[cOoff[0] + 32 + chl]]);
+          const int oc = ocl[cOoff[1] + chl];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) ot[j * 97 + 3 * chl + c] = g * a1[0][c][r] * nrm[oc + c];
+        }
+        wave_sync_lds();
+        for (int lc = lane; lc < 96; lc += 64) {
+          uint32_t off = (uint32_t)(ocol + lc);
+          const float* src = ot + lc;
+          for (int r = 0; r < nrows; ++r) { obase[off] = *src; off += ldo32; src += 97; }
+        }
+        wave_sync_lds();
+        ocol += 96;
+      }
+      if (NT2 > 0) {
+        constexpr int G2 = (NT1 > 0) ? 2 : 1;  // which scalar tile holds the gates of the 2e block
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int chl = chan_of(r);
+          const float g = sigmoid_(a0[NT0 > G2 ? G2 : 0][0][r] * nrm[ocl[cOoff[0] + 32 * G2 + chl]]);
+          const int oc = ocl[cOoff[2] + chl];
+#pragma unroll
+          for (int c = 0; c < 5; ++c) ot[j * 161 + 5 * chl + c] = g * a2[0][c][r] * nrm[oc + c];
+        }
+        wave_sync_lds();
+        for (int lc = lane; lc < 160; lc += 64) {
+          uint32_t off = (uint32_t)(ocol + lc);
+          const float* src = ot + lc;
+          for (int r = 0; r < nrows; ++r) { obase[off] = *src; off += ldo32; src += 161; }
+        }
+        wave_sync_lds();
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < NT0; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[j * 33 + chan_of(r)] = a0[t][0][r];
+        wave_sync_lds();
+        const int lc = lane & 31, rs = lane >> 5, chn = t * 32 + lc;
+        if (chn < cM[0]) {
+          const int col = ocl[cOoff[0] + chn];
+          const float nm = nrm[col];
+          uint32_t off = (uint32_t)col + rs * ldo32;
+          const float* src = ot + rs * 33 + lc;
+          for (int r = rs; r < nrows; r += 2) { obase[off] = *src * nm; off += 2 * ldo32; src += 2 * 33; }
+        }
+        wave_sync_lds();
+      }
+#pragma unroll
+      for (int t = 0; t < NT1; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) ot[j * 97 + 3 * chan_of(r) + c] = a1[t][c][r];
+        wave_sync_lds();
+        const int width = (cM[1] - t * 32 < 32 ? cM[1] - t * 32 : 32) * 3;
+        for (int lc = lane; lc < width; lc += 64) {
+          const int chl = lc / 3, comp = lc - 3 * chl;
+          const int col = ocl[cOoff[1] + t * 32 + chl] + comp;
+          const float nm = nrm[col];
+          uint32_t off = (uint32_t)col;
+          const float* src = ot + lc;
+          for (int r = 0; r < nrows; ++r) { obase[off] = *src * nm; off += ldo32; src += 97; }
+        }
+        wave_sync_lds();
+      }
+#pragma unroll
+      for (int t = 0; t < NT2; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+          for (int c = 0; c < 5; ++c) ot[j * 161 + 5 * chan_of(r) + c] = a2[t][c][r];
+        wave_sync_lds();
+        const int width = (cM[2] - t * 32 < 32 ? cM[2] - t * 32 : 32) * 5;
+        for (int lc = lane; lc < width; lc += 64) {
+          const int chl = lc / 5, comp = lc - 5 * chl;
+          const int col = ocl[cOoff[2] + t * 32 + chl] + comp;
+          const float nm = nrm[col];
+          uint32_t off = (uint32_t)col;
+          const float* src = ot + lc;
+          for (int r = 0; r < nrows; ++r) { obase[off] = *src * nm; off += ldo32; src += 161; }
+        }
+        wave_sync_lds();
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------
+__global__ void fast_pack_kernel(const float* w0, const float* w1, const float* w2, const float* n0, const float* n1,
+                                 const float* n2, float* packed, FDev d, const FPack* pk, int npk,
+                                 const int32_t* ocol_tab) {
+  const float* w[3] = {w0, w1, w2};
+  const float* nr[3] = {n0, n1, n2};
+  for (int r = blockIdx.x; r < npk; r += gridDim.x) {
+    const FPack q = pk[r];
+    const int M = d.M[q.l3], Mpad = d.Mpad[q.l3];
+    for (int i = threadIdx.x; i < q.count * M; i += blockDim.x) {
+      int k = i / M, mm = i - k * M;
+      packed[d.woff[q.l3] + (size_t)(q.wrow + k) * Mpad + mm] = w[q.l3][(int64_t)(q.orig_row + k) * M + mm];
+    }
+  }
+  if (blockIdx.x == 0)
+    for (int l3 = 0; l3 < 3; ++l3) {
+      const int width = 2 * l3 + 1;
+      for (int i = threadIdx.x; i < d.M[l3] * width; i += blockDim.x) {
+        int mm = i / width, comp = i - mm * width;
+        packed[d.wtotal + ocol_tab[d.ooff[l3] + mm] + comp] = nr[l3] ? nr[l3][i] : 1.0f;
+      }
+    }
+}
+
+struct FastKernelEntry {
+  int lsh, nt0, nt1, nt2;
+  std::vector<int> l1s;
+  const void* fn[2][2];  // [wlds][gate]
+};
+#define E3_FAST(LSH, a, b, c, ...)                                                                     \
+  {LSH, a, b, c, {__VA_ARGS__},                                                                         \
+   {{(const void*)tp_fwd_mfma_kernel<LSH, a, b, c, false, false, __VA_ARGS__>,                          \
+     (const void*)tp_fwd_mfma_kernel<LSH, a, b, c, false, true, __VA_ARGS__>},                          \
+    {(const void*)tp_fwd_mfma_kernel<LSH, a, b, c, true, false, __VA_ARGS__>,                           \
+     (const void*)tp_fwd_mfma_kernel<LSH, a, b, c, true, true, __VA_ARGS__>}}}
+// Instantiated signatures = the tensor products of the SEGNN forward (H <= 32 per block):
+//   l_max 1: embed (0,1 -> hid), msg1 (0,1,0,1,0 -> gated), msg2 (0,1 -> gated), upd1 (0,1,0,1 -> gated),
+//            upd2 (0,1 -> hid), readout (0,1 -> 1o);   l_max 2: the same with (0,1,2) blocks.
+static const std::vector<FastKernelEntry>& fast_kernels() {
+  static const std::vector<FastKernelEntry> k = {
+      E3_FAST(1, 1, 1, 0, 0, 1),          E3_FAST(1, 2, 1, 0, 0, 1, 0, 1, 0), E3_FAST(1, 2, 1, 0, 0, 1),
+      E3_FAST(1, 2, 1, 0, 0, 1, 0, 1),    E3_FAST(1, 0, 1, 0, 0, 1),
+      E3_FAST(2, 1, 1, 1, 0, 1),          E3_FAST(2, 3, 1, 1, 0, 1, 2, 0, 1, 2, 0), E3_FAST(2, 3, 1, 1, 0, 1, 2),
+      E3_FAST(2, 3, 1, 1, 0, 1, 2, 0, 1, 2), E3_FAST(2, 1, 1, 1, 0, 1, 2),  E3_FAST(2, 0, 1, 0, 0, 1, 2),
+  };
+  return k;
+}
+
+static const FastKernelEntry* find_fast(int lsh, int a, int b, int c, const std::vector<int>& l1s) {
+  for (auto& e : fast_kernels())
+    if (e.lsh == lsh && e.nt0 == a && e.nt1 == b && e.nt2 == c && e.l1s == l1s) return &e;
+  return nullptr;
+}
+
+int fast_plan_init(TpFast* F, const int n[6], const int M[6], int lmax_sh, int Dout, int Dy,
+                   const std::vector<std::array<int, 4>>& in_blocks /* l,p,mul,col */,
+                   const std::vector<TpPath>* paths_by_class /*[6]*/, const int ocol_off[6]) {
+  F->usable = false;
+  if (n[1] || n[2] || n[5] || M[1] || M[2] || M[5]) return E3_OK;  // natural parity only
+  const int cls3[3] = {0, 3, 4};
+  FDev& d = F->dev;
+  d.Dout = Dout; d.Dy = Dy;
+  int ntab = 0;
+  for (int c = 0; c < 6; ++c) ntab += M[c];
+  d.ntab = ntab;
+  for (int l3 = 0; l3 < 3; ++l3) {
+    d.M[l3] = M[cls3[l3]];
+    d.NT[l3] = (d.M[l3] + 31) / 32;
+    d.Mpad[l3] = d.NT[l3] * 32;
+    d.ooff[l3] = ocol_off[cls3[l3]];
+  }
+  d.lsh = lmax_sh;
+  int next_row[3] = {0, 0, 0};
+  int chan_seen[3] = {0, 0, 0};  // channels of in class l1 seen so far
+  for (auto& b : in_blocks) {
+    const int l1 = b[0], mul = b[2];
+    for (int c0 = 0; c0 < mul; c0 += 32) {
+      FChunk ch;
+      ch.col = b[3] + c0 * (2 * l1 + 1);
+      ch.count = std::min(32, mul - c0);
+      ch.l1 = l1;
+      for (int l2 = 0; l2 < 3; ++l2)
+        for (int l3 = 0; l3 < 3; ++l3) {
+          ch.wrow[l2][l3] = -1;
+          if (l2 > lmax_sh || d.M[l3] == 0 || ((l1 + l2 + l3) & 1) || l3 < std::abs(l1 - l2) || l3 > l1 + l2) continue;
+          // original row offset of path (l1,l2) in class cls3[l3]
+          int orig = -1;
+          for (auto& p : paths_by_class[cls3[l3]])
+            if (p.l1 == l1 && p.l2 == l2) orig = p.wrow;
+          if (orig < 0) continue;
+          ch.wrow[l2][l3] = next_row[l3];
+          F->h_pack.push_back({l3, orig + chan_seen[l1] + 0, ch.count, next_row[l3]});
+          next_row[l3] += (ch.count + 1) & ~1;
+        }
+      chan_seen[l1] += ch.count;
+      F->h_chunks.push_back(ch);
+    }
+  }
+  int woff = 0;
+  for (int l3 = 0; l3 < 3; ++l3) {
+    d.woff[l3] = woff;
+    woff += next_row[l3] * d.Mpad[l3];
+  }
+  d.wtotal = woff;
+  d.nchunks = (int)F->h_chunks.size();
+  if (d.nchunks == 0 || d.wtotal == 0) return E3_OK;
+  std::vector<int> l1s;
+  for (auto& c : F->h_chunks) l1s.push_back(c.l1);
+  if (!find_fast(lmax_sh, d.NT[0], d.NT[1], d.NT[2], l1s)) return E3_OK;
+  // LDS plan
+  size_t tables = (size_t)((Dout + 15) & ~15) * 4 + (size_t)((ntab + 15) & ~15) * 4;
+  size_t wbytes = (size_t)d.wtotal * 4;
+  auto per_wave = [&](int nbuf) { return (size_t)(nbuf * kChunkFloats + 320) * 4; };
+  int nw_w2 = (tables + wbytes + per_wave(2) <= (size_t)kFastLds) ? (int)((kFastLds - tables - wbytes) / per_wave(2)) : 0;
+  if (nw_w2 >= 3) { d.w_in_lds = 1; d.nbuf = 2; d.nwaves = std::min(nw_w2, 4); }
+  else {
+    int nw_w1 = (tables + wbytes + per_wave(1) <= (size_t)kFastLds) ? (int)((kFastLds - tables - wbytes) / per_wave(1)) : 0;
+    if (nw_w1 >= 4) { d.w_in_lds = 1; d.nbuf = 1; d.nwaves = 4; }
+    else { d.w_in_lds = 0; d.nbuf = 1; d.nwaves = std::min((int)((kFastLds - tables) / per_wave(1)), 4); }
+  }
+  if (const char* e = getenv("E3_TP_NBUF")) { int v = atoi(e); if (v == 1 || (v == 2 && d.w_in_lds)) d.nbuf = v; }
+  F->lds_bytes = tables + (d.w_in_lds ? wbytes : 0) + (size_t)d.nwaves * per_wave(d.nbuf);
+  if (F->lds_bytes > (size_t)kFastLds || d.nwaves < 1) return E3_OK;
+  F->usable = true;
+  return E3_OK;
+}
+
+int fast_upload(TpFast* F) {
+  if (!F->usable || F->d_dev) return E3_OK;
+  E3_HIP_CHECK(hipMalloc((void**)&F->d_chunks, F->h_chunks.size() * sizeof(FChunk)));
+  E3_HIP_CHECK(hipMemcpy(F->d_chunks, F->h_chunks.data(), F->h_chunks.size() * sizeof(FChunk), hipMemcpyHostToDevice));
+  E3_HIP_CHECK(hipMalloc((void**)&F->d_pack, std::max<size_t>(F->h_pack.size(), 1) * sizeof(FPack)));
+  if (!F->h_pack.empty())
+    E3_HIP_CHECK(hipMemcpy(F->d_pack, F->h_pack.data(), F->h_pack.size() * sizeof(FPack), hipMemcpyHostToDevice));
+  E3_HIP_CHECK(hipMalloc((void**)&F->d_dev, sizeof(FDev)));
+  E3_HIP_CHECK(hipMemcpy(F->d_dev, &F->dev, sizeof(FDev), hipMemcpyHostToDevice));
+  for (auto& e : fast_kernels())
+    for (int a = 0; a < 2; ++a)
+      for (int b = 0; b < 2; ++b)
+        E3_HIP_CHECK(hipFuncSetAttribute(e.fn[a][b], hipFuncAttributeMaxDynamicSharedMemorySize, kFastLds));
+  return E3_OK;
+}
+
+void fast_free(TpFast* F) {
+  if (F->d_chunks) (void)hipFree(F->d_chunks);
+  if (F->d_pack) (void)hipFree(F->d_pack);
+  if (F->d_dev) (void)hipFree(F->d_dev);
+}
+
+int64_t fast_packed_bytes(const TpFast* F) {
+  return F->usable ? ((int64_t)(F->dev.wtotal + F->dev.Dout) * 4 + 255) / 256 * 256 : 0;
+}
+
+int fast_pack(const TpFast* F, const void* const w[6], const void* const n[6], void* packed, const int32_t* ocol_tab,
+              hipStream_t s) {
+  if (!F->usable) return E3_OK;
+  E3_HIP_CHECK(hipMemsetAsync(packed, 0, (size_t)F->dev.wtotal * 4, s));
+  int npk = (int)F->h_pack.size();
+  hipLaunchKernelGGL(fast_pack_kernel, dim3(std::max(1, std::min(npk, 256))), dim3(256), 0, s, (const float*)w[0],
+                     (const float*)w[3], (const float*)w[4], (const float*)(n ? n[0] : nullptr),
+                     (const float*)(n ? n[3] : nullptr), (const float*)(n ? n[4] : nullptr), (float*)packed, F->dev,
+                     F->d_pack, npk, ocol_tab);
+  E3_HIP_CHECK(hipGetLastError());
+  return E3_OK;
+}
+
+int fast_forward(const TpFast* F, const e3_tp_segment* segs, int nseg, int D1, const void* in2, int64_t ld2,
+                 const void* packed, void* out, int64_t ldo, int64_t B, int gate, const int32_t* ocol_tab,
+                 hipStream_t s) {
+  if (!F->usable) return E3_ERR_UNSUPPORTED;
+  const FDev& d = F->dev;
+  if (nseg < 1 || nseg > 4) return E3_ERR_INVALID_ARG;
+  SegArgs sa;
+  int col = 0;
+  for (int i = 0; i < 4; ++i) { sa.base[i] = nullptr; sa.ld[i] = 0; sa.index[i] = nullptr; }
+  for (int i = 0; i < nseg; ++i) {
+    if (!segs[i].base || segs[i].ncols <= 0 || segs[i].ld < segs[i].ncols) return E3_ERR_INVALID_ARG;
+    sa.base[i] = (const float*)segs[i].base;
+    sa.ld[i] = segs[i].ld;
+    sa.index[i] = segs[i].row_index;
+    sa.col0[i] = col;
+    col += segs[i].ncols;
+  }
+  for (int i = nseg; i < 5; ++i) sa.col0[i] = col;
+  sa.nseg = nseg;
+  if (col != D1) return E3_ERR_INVALID_ARG;
+  for (auto& ch : F->h_chunks) {  // a chunk must not straddle two segments
+    int cw = ch.count * (2 * ch.l1 + 1), sidx = 0;
+    while (sidx + 1 < nseg && ch.col >= sa.col0[sidx + 1]) ++sidx;
+    if (ch.col + cw > sa.col0[sidx + 1]) return E3_ERR_INVALID_ARG;
+  }
+  if (gate) {
+    const int nb = (d.NT[1] > 0) + (d.NT[2] > 0);
+    if (d.NT[0] != 1 + nb || d.M[0] != 32 * (1 + nb) || (d.NT[1] && d.M[1] != 32) || (d.NT[2] && d.M[2] != 32) ||
+        d.NT[1] > 1 || d.NT[2] > 1)
+      return E3_ERR_UNSUPPORTED;
+  }
+  std::vector<int> l1s;
+  for (auto& c : F->h_chunks) l1s.push_back(c.l1);
+  const FastKernelEntry* e = find_fast(d.lsh, d.NT[0], d.NT[1], d.NT[2], l1s);
+  if (!e) return E3_ERR_UNSUPPORTED;
+  int64_t ntiles = (B + 31) / 32;
+  int grid = (int)std::min<int64_t>((ntiles + d.nwaves - 1) / d.nwaves, 256);
+  const float* in2f = (const float*)in2;
+  const float* pk = (const float*)packed;
+  float* outf = (float*)out;
+  const FDev* dd = F->d_dev;
+  const FChunk* dc = F->d_chunks;
+  void* args[] = {&sa, &in2f, &ld2, &pk, &outf, &ldo, &B, &dd, &dc, &ocol_tab};
+  E3_HIP_CHECK(hipLaunchKernel(e->fn[d.w_in_lds ? 1 : 0][gate ? 1 : 0], dim3(grid), dim3(64 * d.nwaves), args,
+                               F->lds_bytes, s));
+  return E3_OK;
+}
+
+}  // namespace e3

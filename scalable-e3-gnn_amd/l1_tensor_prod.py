@@ -161,6 +161,7 @@ class L1TensorProduct(Module):
         out_var = _vars(out_var, len(self.iro), "Len of out_var must be equal to len(irreps_out)")
 
         self._plan = None
+        self._tpplan = None
         self._packed = None
         self._packed_key = None
         self.kernel = 0  # 0 auto, 1 generic, 2 MFMA (see e3_l1tp_forward)
@@ -313,6 +314,23 @@ class L1TensorProduct(Module):
                 g_in2.data_ptr() if g_in2 is not None else None,
                 _lib.ptr4([g_w[c] for c in _CLS]), work.data_ptr(), B, code, stream), "e3_l1tp_backward")
         return g_in1, g_in2, g_w
+
+    # ------------------------------------------------------------------------------------------
+    # Fused message-function form (builder-defined extension; same arithmetic, same weights): the row gather
+    # / concat of in1 and the SEGNN gate run inside the kernel (e3_tp_forward_fused, lmax_sh = 1).
+    def _fused_plan(self):
+        if getattr(self, "_tpplan", None) is None:
+            from .tensor_product import TPPlan
+            self._tpplan = TPPlan(self.iri1, self.iro, 1)
+        return self._tpplan
+
+    def fused_supported(self, gate: bool) -> bool:
+        return self._fused_plan().fused_supported(gate)
+
+    def forward_fused(self, segments, in2: Tensor, gate: bool = False) -> Tensor:
+        ws = self._weights() + [None, None]
+        ns = self._norms() + [None, None]
+        return self._fused_plan().forward_fused(ws, ns, segments, in2, gate, tag=f"{self.iri1}->{self.iro}")
 
     # ------------------------------------------------------------------------------------------
     def forward(self, in1: Tensor, in2: Tensor) -> Tensor:

@@ -30,9 +30,15 @@ class RadiusGraph:
 
     @property
     def dst(self) -> torch.Tensor:
-        n = self.rowptr.numel() - 1
-        deg = (self.rowptr[1:] - self.rowptr[:-1]).long()
-        return torch.repeat_interleave(torch.arange(n, device=self.src.device, dtype=torch.int32), deg)
+        """[E] int32 destination of every edge (expanded from rowptr once, then cached)."""
+        d = getattr(self, "_dst", None)
+        if d is None:
+            n = self.rowptr.numel() - 1
+            deg = (self.rowptr[1:] - self.rowptr[:-1]).long()
+            d = torch.repeat_interleave(torch.arange(n, device=self.src.device, dtype=torch.int32), deg,
+                                        output_size=self.num_edges)
+            object.__setattr__(self, "_dst", d)
+        return d
 
 
 def grid_params(lo, hi, r) -> RgParams:

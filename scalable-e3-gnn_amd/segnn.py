@@ -47,6 +47,7 @@ class SEGNNLayer(nn.Module):
         super().__init__()
         hid, gated = _hidden_irreps(H, lmax)
         self.H, self.lmax = H, lmax
+        self.fused = True  # use the fused gather+TP+gate kernel when the shapes allow it
         self.msg1 = _make_tp(hid + hid + Irreps("1x0e"), gated, lmax)
         self.msg2 = _make_tp(hid, gated, lmax)
         self.upd1 = _make_tp(hid + hid, gated, lmax)
@@ -56,7 +57,23 @@ class SEGNNLayer(nn.Module):
         H = self.H
         return ops.gate(t, H, H) if self.lmax == 1 else ops.gate_blocks(t, H, [(1, H), (2, H)])
 
+    def _fused(self) -> bool:
+        f = getattr(self, "_fused_ok", None)
+        if f is None:
+            f = (self.H == 32 and not torch.is_grad_enabled() and
+                 all(tp.fused_supported(True) for tp in (self.msg1, self.msg2, self.upd1)))
+            self._fused_ok = f
+        return f and not torch.is_grad_enabled()
+
     def forward(self, h, g: RadiusGraph, Y, d, A):
+        if self.fused and self._fused():
+            # gather + concat + TP + gate in one kernel each: no [E, 2D+1] / raw-TP tensors in HBM
+            m = self.msg1.forward_fused([(h, g.dst), (h, g.src), (d, None)], Y, gate=True)
+            m = self.msg2.forward_fused([(m, None)], Y, gate=True)
+            a = ops.segment_sum(m, g)
+            u = self.upd1.forward_fused([(h, None), (a, None)], A, gate=True)
+            u = self.upd2(u, A)
+            return h + u
         m = ops.gather_concat(h, g, d)
         m = self._gate(self.msg1(m, Y))
         m = self._gate(self.msg2(m, Y))

@@ -20,6 +20,107 @@ from .irreps import Irreps, as_blocks
 CLASSES = ("l0e", "l0o", "l1e", "l1o", "l2e", "l2o")
 
 
+class TPSegment(ctypes.Structure):
+    _fields_ = [("base", ctypes.c_void_p), ("ld", ctypes.c_int64), ("row_index", ctypes.c_void_p),
+                ("ncols", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+class TPPlan:
+    """One ``e3_tp_plan*`` plus its packed-weight cache; shared by ``SHTensorProduct`` and by
+    ``L1TensorProduct.forward_fused`` (the l <= 1 operator is the lmax_sh = 1 special case)."""
+
+    def __init__(self, in1_irreps, out_irreps, lmax_sh):
+        lib = _lib.load()
+        a, na = _lib.blocks_array(as_blocks(in1_irreps))
+        b, nb = _lib.blocks_array(as_blocks(out_irreps))
+        self.handle = ctypes.c_void_p()
+        _lib.check(lib.e3_tp_plan_create(a, na, lmax_sh, b, nb, ctypes.byref(self.handle)), "e3_tp_plan_create")
+        self._destroy = lib.e3_tp_plan_destroy
+        self.in1_dim = lib.e3_tp_in1_dim(self.handle)
+        self.in2_dim = lib.e3_tp_in2_dim(self.handle)
+        self.out_dim = lib.e3_tp_out_dim(self.handle)
+        self._packed = None
+        self._key = None
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self._destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def fused_supported(self, gate: bool) -> bool:
+        return bool(_lib.load().e3_tp_fused_supported(self.handle, 1 if gate else 0))
+
+    def packed(self, ws, ns, dtype, device):
+        """ws / ns: 6-entry lists (per class) of optional tensors."""
+        key = (dtype, device) + tuple((t.data_ptr(), t._version) if t is not None else None for t in ws + ns)
+        if self._packed is not None and self._key == key:
+            return self._packed
+        lib = _lib.load()
+        code = _lib.dtype_code(dtype)
+        for t in ws + ns:
+            if t is not None and t.numel() and (t.dtype != dtype or t.device != device):
+                raise RuntimeError(f"tensor product: parameter {t.dtype}/{t.device} vs input {dtype}/{device}")
+        nbytes = lib.e3_tp_packed_bytes(self.handle, code)
+        if nbytes < 0:
+            raise RuntimeError(f"tensor product supports float32/float64, got {dtype}")
+        packed = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        P6 = ctypes.c_void_p * 6
+        ptr = lambda t: t.data_ptr() if (t is not None and t.numel()) else None
+        wsc = [w.detach().contiguous() if w is not None else None for w in ws]
+        nsc = [n.detach().contiguous() if n is not None else None for n in ns]
+        stream = torch.cuda.current_stream(device).cuda_stream
+        _lib.check(lib.e3_tp_pack_weights(self.handle, P6(*map(ptr, wsc)), P6(*map(ptr, nsc)), code,
+                                          packed.data_ptr(), stream), "e3_tp_pack_weights")
+        self._packed, self._key = packed, key
+        return packed
+
+    def forward_fused(self, ws, ns, segments, in2, gate: bool, tag=""):
+        """segments: [(tensor [R, ncols] fp32, row_index int32 [B] | None), ...]; -> [B, out_dim or gated width]"""
+        lib = _lib.load()
+        B = in2.shape[0]
+        dev = in2.device
+        segs = (TPSegment * len(segments))()
+        keep = []
+        for i, (t, idx) in enumerate(segments):
+            if t.dtype != torch.float32 or not t.is_cuda:
+                raise RuntimeError("forward_fused: float32 ROCm tensors required")
+            if t.dim() == 1:
+                t = t.unsqueeze(1)
+            if t.stride(-1) != 1:
+                t = t.contiguous()
+            keep.append(t)
+            segs[i].base, segs[i].ld, segs[i].ncols = t.data_ptr(), t.stride(0), t.shape[1]
+            if idx is not None:
+                assert idx.dtype == torch.int32 and idx.numel() == B
+                segs[i].row_index = idx.data_ptr()
+            else:
+                assert t.shape[0] == B
+        width = self.out_dim
+        if gate:
+            ngated = (self.out_dim - 32) // 4 if self.out_dim in (160, ) else None
+            width = {160: 128, 352: 288, 224: 192}.get(self.out_dim)
+            if width is None:
+                raise RuntimeError("gate fusion needs out irreps [32x0e | 32x0e per block | 32x1o | 32x2e]")
+        out = torch.empty((B, width), dtype=torch.float32, device=dev)
+        if B == 0:
+            return out
+        if in2.stride(-1) != 1:
+            in2 = in2.contiguous()
+        with torch.cuda.device(dev):
+            packed = self.packed(ws, ns, torch.float32, dev)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            t0 = profiling.begin() if profiling.enabled() else None
+            _lib.check(lib.e3_tp_forward_fused(self.handle, ctypes.byref(segs), len(segments), in2.data_ptr(),
+                                               in2.stride(0), packed.data_ptr(), out.data_ptr(), out.stride(0), B,
+                                               _lib.E3_F32, 1 if gate else 0, stream), "e3_tp_forward_fused")
+            if t0 is not None:
+                profiling.end(f"tp_fused {tag} B={B}", B, 4 * (self.in1_dim + self.in2_dim + width) * B, t0)
+        return out
+
+
 class SHTensorProduct(nn.Module):
     def __init__(self, in1_irreps, out_irreps, lmax_sh: int = 2):
         super().__init__()
@@ -28,14 +129,9 @@ class SHTensorProduct(nn.Module):
         self.iri2 = Irreps.spherical_harmonics(lmax_sh)
         self.lmax_sh = lmax_sh
         lib = _lib.load()
-        a, na = _lib.blocks_array(as_blocks(self.iri1))
-        b, nb = _lib.blocks_array(as_blocks(self.iro))
-        self._handle = ctypes.c_void_p()
-        _lib.check(lib.e3_tp_plan_create(a, na, lmax_sh, b, nb, ctypes.byref(self._handle)), "e3_tp_plan_create")
-        self._destroy = lib.e3_tp_plan_destroy
-        self.in1_dim = lib.e3_tp_in1_dim(self._handle)
-        self.in2_dim = lib.e3_tp_in2_dim(self._handle)
-        self.out_dim = lib.e3_tp_out_dim(self._handle)
+        self._plan = TPPlan(self.iri1, self.iro, lmax_sh)
+        self._handle = self._plan.handle
+        self.in1_dim, self.in2_dim, self.out_dim = self._plan.in1_dim, self._plan.in2_dim, self._plan.out_dim
         for ci, c in enumerate(CLASSES):
             rows, cols = ctypes.c_int(), ctypes.c_int()
             lib.e3_tp_weight_shape(self._handle, ci, ctypes.byref(rows), ctypes.byref(cols))
@@ -45,17 +141,6 @@ class SHTensorProduct(nn.Module):
             l = ci >> 1
             val = sqrt((2 * l + 1) / rows.value) if rows.value > 0 else 1.0
             self.register_buffer("norm_" + c, torch.full((nlen,), val))
-        self._packed = None
-        self._packed_key = None
-
-    def __del__(self):
-        try:
-            if self._handle:
-                self._destroy(self._handle)
-                self._handle = None
-        except Exception:
-            pass
-
     def _tensors(self):
         ws = [getattr(self, "weights_" + c, None) for c in CLASSES]
         ns = [getattr(self, "norm_" + c) for c in CLASSES]
@@ -63,26 +148,15 @@ class SHTensorProduct(nn.Module):
 
     def _packed_weights(self, dtype, device):
         ws, ns = self._tensors()
-        key = (dtype, device) + tuple((t.data_ptr(), t._version) if t is not None else None for t in ws + ns)
-        if self._packed is not None and self._packed_key == key:
-            return self._packed
-        lib = _lib.load()
-        code = _lib.dtype_code(dtype)
-        for t in ws + ns:
-            if t is not None and t.numel() and (t.dtype != dtype or t.device != device):
-                raise RuntimeError(f"SHTensorProduct: parameter {t.dtype}/{t.device} vs input {dtype}/{device}")
-        nbytes = lib.e3_tp_packed_bytes(self._handle, code)
-        if nbytes < 0:
-            raise RuntimeError(f"SHTensorProduct supports float32/float64, got {dtype}")
-        packed = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
-        P6 = ctypes.c_void_p * 6
-        ptr = lambda t: t.data_ptr() if (t is not None and t.numel()) else None
-        wsc = [w.detach().contiguous() if w is not None else None for w in ws]
-        stream = torch.cuda.current_stream(device).cuda_stream
-        _lib.check(lib.e3_tp_pack_weights(self._handle, P6(*map(ptr, wsc)), P6(*map(ptr, ns)), code,
-                                          packed.data_ptr(), stream), "e3_tp_pack_weights")
-        self._packed, self._packed_key = packed, key
-        return packed
+        return self._plan.packed(ws, ns, dtype, device)
+
+    def fused_supported(self, gate: bool) -> bool:
+        return self._plan.fused_supported(gate)
+
+    def forward_fused(self, segments, in2, gate: bool = False):
+        """TP over ``in1 = [seg0[idx0] | seg1[idx1] | ...]`` (gather + concat fused), optional fused gate."""
+        ws, ns = self._tensors()
+        return self._plan.forward_fused(ws, ns, segments, in2, gate, tag=f"{self.iri1}->{self.iro}")
 
     def forward(self, in1: torch.Tensor, in2: torch.Tensor) -> torch.Tensor:
         torch._assert(in1.shape[-1] == self.in1_dim,

@@ -108,3 +108,25 @@ def test_segnn_lmax2_forward_vs_oracle():
     want = S.forward_l2(params, H, L, "1x0e+1x1o", "1x1o", xs.double().numpy(), pos.numpy()[perm],
                         g.rowptr.cpu().numpy(), g.src.cpu().numpy())
     assert rel(out, want) < 1e-4, rel(out, want)
+
+
+def test_segnn_lmax2_fused_H32_vs_oracle():
+    """H = 32 takes the fused MFMA path (gather + TP + gate in one kernel); small cloud, 1 layer."""
+    N, H, L = 300, 32, 1
+    torch.manual_seed(8)
+    pos = torch.rand(N, 3, generator=torch.Generator().manual_seed(8))
+    r = float((3 * 10.0 / (4 * np.pi * N)) ** (1 / 3))
+    model = SEGNN("1x0e+1x1o", H, "1x1o", L, lmax=2).to(DEV)
+    g = radius_graph(pos.to(DEV), r, [0, 0, 0], [1, 1, 1])
+    xs = torch.randn(N, 4, generator=torch.Generator().manual_seed(9))[g.perm.cpu().long()]
+    with torch.no_grad():
+        assert model.layers[0]._fused()
+        out = model(xs.to(DEV), g)
+        model.layers[0].fused = False
+        out_unfused = model(xs.to(DEV), g)
+    assert rel(out, out_unfused.double().cpu().numpy()) < 1e-5
+    params = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    perm = g.perm.cpu().numpy()
+    want = S.forward_l2(params, H, L, "1x0e+1x1o", "1x1o", xs.double().numpy(), pos.numpy()[perm],
+                        g.rowptr.cpu().numpy(), g.src.cpu().numpy())
+    assert rel(out, want) < 1e-4, rel(out, want)
