@@ -27,7 +27,8 @@ import numpy as np
 import torch
 
 METRIC = "particles/sec (octree build + SEGNN fwd), 1M pts l_max=2, 1/2/4/8 MI355X"
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_F32_PEAK_TF = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA (v_mfma_f32_32x32x2_f32) dense peak
 
 
 def cutoff(n, k=24.0):
@@ -168,11 +169,26 @@ def main():
         ms = dt / args.steps * 1e3
         total_particles = n * world
         dom_tag, dom = max(prof.items(), key=lambda kv: kv[1]["total_ms"])
-        achieved = dom["bytes_per_launch"] / (dom["avg_ms"] * 1e-3) / 1e9
+        sec = dom["avg_ms"] * 1e-3
+        gbs = dom["bytes_per_launch"] / sec / 1e9
+        tfs = dom["flops_per_launch"] / sec / 1e12
+        # the bounding roofline of this kernel = whichever limit gives the longer minimum time
+        mfma_bound = dom["flops_per_launch"] / (MFMA_F32_PEAK_TF * 1e12) > dom["bytes_per_launch"] / (HBM_PEAK_GBS * 1e9)
         traffic = None
         tpath = os.path.join(REPO, "profiles", f"r01_traffic_lmax{args.lmax}.json")
         if os.path.exists(tpath):
             traffic = json.load(open(tpath)).get("dominant_kernel_hbm_bytes_per_launch")
+        roof = {"bound": "mfma" if mfma_bound else "hbm", "kernel": dom["kernel"] + "  [" + dom_tag + "]",
+                "achieved": tfs if mfma_bound else gbs, "peak": MFMA_F32_PEAK_TF if mfma_bound else HBM_PEAK_GBS,
+                "unit": "TFLOP/s" if mfma_bound else "GB/s",
+                "frac": (tfs / MFMA_F32_PEAK_TF) if mfma_bound else (gbs / HBM_PEAK_GBS), "traffic": traffic,
+                "avg_launch_ms": dom["avg_ms"], "launches": dom["launches"],
+                "algorithmic_bytes_per_launch": dom["bytes_per_launch"],
+                "algorithmic_flops_per_launch": dom["flops_per_launch"],
+                "algorithmic_GBps": gbs, "algorithmic_TFLOPps": tfs,
+                "tp_share_of_step": sum(v["total_ms"] for v in prof.values()) / (dt * 1e3)}
+        if args.timing_json:
+            json.dump(prof, open(args.timing_json, "w"), indent=1)
         line = {
             "metric": METRIC, "value": total_particles / (dt / args.steps), "unit": "particles/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
@@ -184,11 +200,7 @@ def main():
                        "layers": args.layers, "lmax": args.lmax,
                        "parallelism": (f"spatial slabs x{world}, ghost halo width r, 1 position + {args.layers} feature "
                                        f"p2p exchanges/step over RCCL") if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "kernel": ("e3::l1tp_fwd_mfma_kernel" if args.lmax == 1 else "e3::tp_fwd_generic_kernel") + "  [" + dom_tag + "]",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "avg_launch_ms": dom["avg_ms"], "launches": dom["launches"],
-                         "algorithmic_bytes_per_launch": dom["bytes_per_launch"],
-                         "l1tp_share_of_step": sum(v["total_ms"] for v in prof.values()) / (dt * 1e3)},
+            "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, model.state_dict())

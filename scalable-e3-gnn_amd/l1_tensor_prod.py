@@ -278,7 +278,11 @@ class L1TensorProduct(Module):
                        "e3_l1tp_forward")
             if t0 is not None:
                 tag = f"l1tp_fwd {self.iri1}->{self.iro} B={B}"
-                profiling.end(tag, B, in1.element_size() * (self.in1_dim + 4 + out.shape[1]) * B, t0)
+                n0e, n0o, n1e, n1o = self.num_i1_l0e, self.num_i1_l0o, self.num_i1_l1e, self.num_i1_l1o
+                fl = (2 * (n0e + n1o) * self.dim_o_l0e + 2 * (n0o + n1e) * self.dim_o_l0o +
+                      2 * (n0o + 3 * n1e + 3 * n1o) * (self.dim_o_l1e // 3) + 2 * (n0e + 3 * n1o + 3 * n1e) * (self.dim_o_l1o // 3))
+                profiling.end(tag, B, in1.element_size() * (self.in1_dim + 4 + out.shape[1]) * B, t0, flops=fl * B,
+                              kernel="e3::l1tp_fwd_mfma_kernel")
         return out
 
     def _hip_backward(self, in1, in2, grad_out, need_in1, need_in2, need_w):

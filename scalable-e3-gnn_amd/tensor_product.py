@@ -41,6 +41,20 @@ class TPPlan:
         self.out_dim = lib.e3_tp_out_dim(self.handle)
         self._packed = None
         self._key = None
+        # algorithmic flops per row: sum over paths of 2 K M min(2 l1+1, 2 l3+1) (the contraction with W; the
+        # per-row CG/feature algebra is excluded)
+        n, M = {}, {}
+        for l, p, mul in as_blocks(in1_irreps):
+            n[(l, p)] = n.get((l, p), 0) + mul
+        for l, p, mul in as_blocks(out_irreps):
+            M[(l, p)] = M.get((l, p), 0) + mul
+        fl = 0
+        for (l3, p3), m3 in M.items():
+            for (l1, p1), k in n.items():
+                for l2 in range(lmax_sh + 1):
+                    if abs(l1 - l2) <= l3 <= l1 + l2 and p1 * (-1) ** l2 == p3:
+                        fl += 2 * k * m3 * min(2 * l1 + 1, 2 * l3 + 1)
+        self.flops_per_row = fl
 
     def __del__(self):
         try:
@@ -117,7 +131,11 @@ class TPPlan:
                                                in2.stride(0), packed.data_ptr(), out.data_ptr(), out.stride(0), B,
                                                _lib.E3_F32, 1 if gate else 0, stream), "e3_tp_forward_fused")
             if t0 is not None:
-                profiling.end(f"tp_fused {tag} B={B}", B, 4 * (self.in1_dim + self.in2_dim + width) * B, t0)
+                # algorithmic bytes: gathered segments count their SOURCE rows once (re-gathers are cache traffic)
+                nb = sum((t.shape[0] * t.shape[1] * 4 + (4 * B if idx is not None else 0)) for t, idx in
+                         [(k, s[1]) for k, s in zip(keep, segments)]) + 4 * (self.in2_dim + width) * B
+                profiling.end(f"tp_fused {tag} B={B}", B, nb, t0, flops=self.flops_per_row * B,
+                              kernel="e3::tp_fwd_mfma_kernel")
         return out
 
 
@@ -187,5 +205,8 @@ class SHTensorProduct(nn.Module):
                                          _lib.dtype_code(in1.dtype), stream), "e3_tp_forward")
             if t0 is not None:
                 profiling.end(f"tp_fwd(l<=2) {self.iri1}->{self.iro} B={B}", B,
-                              in1.element_size() * (self.in1_dim + self.in2_dim + self.out_dim) * B, t0)
+                              in1.element_size() * (self.in1_dim + self.in2_dim + self.out_dim) * B, t0,
+                              flops=self._plan.flops_per_row * B,
+                              kernel="e3::tp_fwd_mfma_kernel" if (in1.dtype == torch.float32 and
+                                                                   self._plan.fused_supported(False)) else "e3::tp_fwd_generic_kernel")
         return out
