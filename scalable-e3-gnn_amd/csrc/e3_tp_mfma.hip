@@ -37,24 +37,19 @@ __device__ __forceinline__ void wave_sync_lds() {
   __builtin_amdgcn_wave_barrier();
 }
 
-// contract one staged chunk (class l1) into the accumulators of one output tile of class l3 through SH degree l2
-template <int L1, int L2, int L3>
+// Contract one staged chunk (degree l1) into ALL NT output tiles of degree l3 through SH degree l2.
+// The per-row B features are built once per k-step and shared by the NT tiles (one A load + MFMA set per
+// tile); loads run U steps ahead of the MFMAs so that >= 12 MFMAs (>= 768 cycles) cover an LDS / L2 round trip.
+template <int L1, int L2, int L3, int NT>
 __device__ __forceinline__ void run_steps(const float* __restrict__ xr, const int count, const float* __restrict__ wp,
                                           const int Mpad, const int half, const float (&y)[9],
-                                          f32x16 (&acc)[2 * L3 + 1]) {
+                                          f32x16 (&acc)[NT][2 * L3 + 1]) {
   constexpr int D1 = 2 * L1 + 1, D2 = 2 * L2 + 1, D3 = 2 * L3 + 1;
   constexpr bool MIX = D1 < D3;
-  constexpr int U = (D1 == 1) ? 4 : 2;
+  constexpr int PER_STEP = NT * (MIX ? D1 : D3);
+  constexpr int U = (PER_STEP >= 3) ? 4 : 8;
   using C = CG<L1, L2, L3>;
-  __builtin_amdgcn_sched_barrier(0);  // keep the scheduler from interleaving independent path loops
-  // z is tile-invariant: without this the compiler hoists the z matrices of ALL paths out of the chunk loop and keeps
-  // ~150 VGPRs of them live (spills).  Making Y opaque here pins the (cheap) recomputation next to its use.
-  float yl[D2];
-#pragma unroll
-  for (int b = 0; b < D2; ++b) {
-    yl[b] = y[L2 * L2 + b];
-    asm volatile("" : "+v"(yl[b]));
-  }
+  __builtin_amdgcn_sched_barrier(0);
   float z[D1][D3];
 #pragma unroll
   for (int a = 0; a < D1; ++a)
@@ -63,24 +58,33 @@ __device__ __forceinline__ void run_steps(const float* __restrict__ xr, const in
       float s = 0.f;
 #pragma unroll
       for (int b = 0; b < D2; ++b)
-        if (C::v[a][b][c] != 0.0) s += (float)C::v[a][b][c] * yl[b];
+        if (C::v[a][b][c] != 0.0) s += (float)C::v[a][b][c] * y[L2 * L2 + b];
       z[a][c] = s;
     }
-  f32x16 T[MIX ? D1 : 1];
+  f32x16 T[MIX ? NT : 1][MIX ? D1 : 1];
   if (MIX) {
 #pragma unroll
-    for (int a = 0; a < D1; ++a) T[a] = f32x16{0};
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int a = 0; a < D1; ++a) T[t][a] = f32x16{0};
   }
   const float* xp = xr + half * D1;
-  auto load = [&](int p, float& a, float (&x)[D1]) {
-    a = wp[(2 * p) * Mpad];
+  auto load = [&](int p, float (&a)[NT], float (&x)[D1]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) a[t] = wp[(2 * p) * Mpad + 32 * t];
 #pragma unroll
     for (int m = 0; m < D1; ++m) x[m] = xp[2 * p * D1 + m];
   };
-  auto step = [&](float a, const float (&x)[D1], bool valid) {
+  auto step = [&](const float (&a)[NT], const float (&x)[D1], auto validtag) {
+    constexpr bool ALWAYS = decltype(validtag)::value;
+    const bool valid = ALWAYS || (half == 0);
     if (MIX) {
 #pragma unroll
-      for (int m = 0; m < D1; ++m) T[m] = mfma32(a, valid ? x[m] : 0.f, T[m]);
+      for (int m = 0; m < D1; ++m) {
+        const float b = valid ? x[m] : 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) T[t][m] = mfma32(a[t], b, T[t][m]);
+      }
     } else {
 #pragma unroll
       for (int c = 0; c < D3; ++c) {
@@ -92,52 +96,57 @@ __device__ __forceinline__ void run_steps(const float* __restrict__ xr, const in
           for (int q = 0; q < D2; ++q) nz |= (C::v[m][q][c] != 0.0);
           if (nz) b += z[m][c] * x[m];
         }
-        acc[c] = mfma32(a, valid ? b : 0.f, acc[c]);
+        if (!valid) b = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t][c] = mfma32(a[t], b, acc[t][c]);
       }
     }
   };
   const int npair = count >> 1;
   const int ngrp = npair / U;
   if (ngrp > 0) {
-    float a[U], x[U][D1];
+    float a[U][NT], x[U][D1];
 #pragma unroll
     for (int u = 0; u < U; ++u) load(u, a[u], x[u]);
     for (int g = 1; g < ngrp; ++g) {
-      float an[U], xn[U][D1];
+      float an[U][NT], xn[U][D1];
 #pragma unroll
       for (int u = 0; u < U; ++u) load(g * U + u, an[u], xn[u]);
 #pragma unroll
-      for (int u = 0; u < U; ++u) step(a[u], x[u], true);
+      for (int u = 0; u < U; ++u) step(a[u], x[u], std::true_type{});
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        a[u] = an[u];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) a[u][t] = an[u][t];
 #pragma unroll
         for (int m = 0; m < D1; ++m) x[u][m] = xn[u][m];
       }
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u) step(a[u], x[u], true);
+    for (int u = 0; u < U; ++u) step(a[u], x[u], std::true_type{});
   }
   for (int p = ngrp * U; p < npair; ++p) {
-    float a, x[D1];
+    float a[NT], x[D1];
     load(p, a, x);
-    step(a, x, true);
+    step(a, x, std::true_type{});
   }
-  if (count & 1) {
-    float a, x[D1];
+  if (count & 1) {  // odd tail: the partner k is a zero weight row; its B lane must be a clean 0
+    float a[NT], x[D1];
     load(npair, a, x);
-    step(a, x, half == 0);
+    step(a, x, std::false_type{});
   }
   if (MIX) {
 #pragma unroll
-    for (int c = 0; c < D3; ++c)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int a = 0; a < D1; ++a) {
-        bool nz = false;
+      for (int c = 0; c < D3; ++c)
 #pragma unroll
-        for (int q = 0; q < D2; ++q) nz |= (C::v[a][q][c] != 0.0);
-        if (nz) acc[c] += T[a] * z[a][c];
-      }
+        for (int a = 0; a < D1; ++a) {
+          bool nz = false;
+#pragma unroll
+          for (int q = 0; q < D2; ++q) nz |= (C::v[a][q][c] != 0.0);
+          if (nz) acc[t][c] += T[t][a] * z[a][c];
+        }
   }
   __builtin_amdgcn_sched_barrier(0);
 }
@@ -276,14 +285,12 @@ __global__ __launch_bounds__(256) void tp_fwd_mfma_kernel(SegArgs segs, const fl
       const float* xr = xt + j * (cw | 1);
 #define E3_RUN(L2v, L3v, ACC, NTv)                                                                             \
   if constexpr (NTv > 0 && L2v <= LSH && CG<L1, L2v, L3v>::valid && ((L1 + L2v + L3v) % 2 == 0)) {             \
-    _Pragma("unroll") for (int t = 0; t < NTv; ++t) {                                                          \
-      const float* wp = wsrc + cWoff[L3v] + (size_t)(ch.wrow[L2v][L3v] + half) * cMpad[L3v] + t * 32 + j;     \
-      run_steps<L1, L2v, L3v>(xr, ch.count, wp, cMpad[L3v], half, y, ACC);                                     \
-    }                                                                                                          \
+    const float* wp = wsrc + cWoff[L3v] + (size_t)(ch.wrow[L2v][L3v] + half) * cMpad[L3v] + j;                 \
+    run_steps<L1, L2v, L3v, NTv>(xr, ch.count, wp, cMpad[L3v], half, y, ACC);                                  \
   }
-      E3_RUN(0, 0, a0[t], NT0) E3_RUN(1, 0, a0[t], NT0) E3_RUN(2, 0, a0[t], NT0)
-      E3_RUN(0, 1, a1[t], NT1) E3_RUN(1, 1, a1[t], NT1) E3_RUN(2, 1, a1[t], NT1)
-      E3_RUN(0, 2, a2[t], NT2) E3_RUN(1, 2, a2[t], NT2) E3_RUN(2, 2, a2[t], NT2)
+      E3_RUN(0, 0, a0, NT0) E3_RUN(1, 0, a0, NT0) E3_RUN(2, 0, a0, NT0)
+      E3_RUN(0, 1, a1, NT1) E3_RUN(1, 1, a1, NT1) E3_RUN(2, 1, a1, NT1)
+      E3_RUN(0, 2, a2, NT2) E3_RUN(1, 2, a2, NT2) E3_RUN(2, 2, a2, NT2)
 #undef E3_RUN
       if (nbuf == 1) {
         wave_sync_lds();
