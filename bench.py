@@ -110,7 +110,7 @@ def main():
     if args.lmax not in (1, 2):
         raise SystemExit("l_max must be 1 or 2")
     if args.cpu_sample is None:
-        args.cpu_sample = 20000 if args.lmax == 1 else 6000
+        args.cpu_sample = 20000 if args.lmax == 1 else 16000
 
     n = args.particles
     # One global cloud of world*n particles in [0,world) x [0,1)^2, cut into slabs along x: rank k owns
