@@ -56,9 +56,13 @@ __device__ __forceinline__ void run_steps(const float* __restrict__ xr, const in
 #pragma unroll
     for (int c = 0; c < D3; ++c) {
       float s = 0.f;
+      bool have = false;
 #pragma unroll
       for (int b = 0; b < D2; ++b)
-        if (C::v[a][b][c] != 0.0) s += (float)C::v[a][b][c] * y[L2 * L2 + b];
+        if (C::v[a][b][c] != 0.0) {
+          s = have ? __builtin_fmaf((float)C::v[a][b][c], y[L2 * L2 + b], s) : (float)C::v[a][b][c] * y[L2 * L2 + b];
+          have = true;
+        }
       z[a][c] = s;
     }
   f32x16 T[MIX ? NT : 1][MIX ? D1 : 1];
@@ -89,12 +93,16 @@ __device__ __forceinline__ void run_steps(const float* __restrict__ xr, const in
 #pragma unroll
       for (int c = 0; c < D3; ++c) {
         float b = 0.f;
+        bool have = false;  // folds at compile time: one v_mul then a pure v_fma chain (no "0 + x", no SLP packing)
 #pragma unroll
         for (int m = 0; m < D1; ++m) {
           bool nz = false;
 #pragma unroll
           for (int q = 0; q < D2; ++q) nz |= (C::v[m][q][c] != 0.0);
-          if (nz) b += z[m][c] * x[m];
+          if (nz) {
+            b = have ? __builtin_fmaf(z[m][c], x[m], b) : z[m][c] * x[m];
+            have = true;
+          }
         }
         if (!valid) b = 0.f;
 #pragma unroll
