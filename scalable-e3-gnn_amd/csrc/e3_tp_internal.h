@@ -12,12 +12,17 @@ struct TpPath { int c1, l1, l2, wrow; };
 struct FChunk {  // one piece (<= 32 channels) of an in1 irreps block, natural parity class of degree l1
   int col, count, l1;
   int wrow[3][3];  // [l2][l3]: first packed weight row in class l3's matrix, -1 = no coupling
+  int wblk[3][3];  // same for the bf16-split layout, in blocks of 16 rows
 };
 struct FDev {
   int Dout, Dy, nchunks, nwaves, nbuf, w_in_lds, wtotal, ntab, lsh;
   int M[3], NT[3], Mpad[3], woff[3], ooff[3];  // per output degree l3 (classes 0e, 1o, 2e)
+  // bf16-split variant (BF): weights as hi/lo bf16 in [16-row block][k half][channel][8] order
+  int bf;            // 1 = this plan runs the bf16-split kernel
+  int bfoff[3];      // element offset (uint16) of class l3 inside Whi (and inside Wlo)
+  int bftotal;       // uint16 elements of Whi (== Wlo)
 };
-struct FPack { int l3, orig_row, count, wrow; };
+struct FPack { int l3, orig_row, count, wrow, wblk; };
 
 struct TpFast {
   FDev dev;

@@ -159,6 +159,139 @@ __device__ __forceinline__ void run_steps(const float* __restrict__ xr, const in
   __builtin_amdgcn_sched_barrier(0);
 }
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// bf16-split variant of run_steps: every fp32 operand is written as hi + lo (two bf16 values, 16 significant bits
+// together) and a product is accumulated as hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 (fp32 accumulate):
+// 16 k per instruction instead of 2, 3 instructions of 32 cycles instead of 8 of 64.  Lane (row j, half h) supplies
+// the features of channels 16 kb + 8 h + 0..7 of its own row; the A operand is one 16-byte read of the packed
+// [block][half][channel][8] weight layout.
+template <int L1, int L2, int L3, int NT>
+__device__ __forceinline__ void run_steps_bf(const float* __restrict__ xr, const int count,
+                                             const uint4* __restrict__ whi, const uint4* __restrict__ wlo,
+                                             const int Mpad, const int half, const float (&y)[9],
+                                             f32x16 (&acc)[NT][2 * L3 + 1]) {
+  constexpr int D1 = 2 * L1 + 1, D2 = 2 * L2 + 1, D3 = 2 * L3 + 1;
+  constexpr bool MIX = D1 < D3;
+  constexpr int NB = MIX ? D1 : D3;  // B operands per k block
+  using C = CG<L1, L2, L3>;
+  __builtin_amdgcn_sched_barrier(0);
+  float z[D1][D3];
+#pragma unroll
+  for (int a = 0; a < D1; ++a)
+#pragma unroll
+    for (int c = 0; c < D3; ++c) {
+      float s = 0.f;
+      bool have = false;
+#pragma unroll
+      for (int b = 0; b < D2; ++b)
+        if (C::v[a][b][c] != 0.0) {
+          s = have ? __builtin_fmaf((float)C::v[a][b][c], y[L2 * L2 + b], s) : (float)C::v[a][b][c] * y[L2 * L2 + b];
+          have = true;
+        }
+      z[a][c] = s;
+    }
+  f32x16 T[MIX ? NT : 1][MIX ? D1 : 1];
+  if (MIX) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int a = 0; a < D1; ++a) T[t][a] = f32x16{0};
+  }
+  const float* xp = xr + 8 * half * D1;
+  const int nkb = (count + 15) >> 4;
+  auto load = [&](int kb, uint4 (&ah)[NT], uint4 (&al)[NT], float (&x)[8][D1]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      ah[t] = whi[(2 * kb) * Mpad + 32 * t];
+      al[t] = wlo[(2 * kb) * Mpad + 32 * t];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int m = 0; m < D1; ++m) x[i][m] = xp[(16 * kb + i) * D1 + m];
+  };
+  auto compute = [&](int kb, const uint4 (&ah)[NT], const uint4 (&al)[NT], const float (&x)[8][D1]) {
+    const int kleft = count - (16 * kb + 8 * half);  // channels of this lane's half that are real
+#pragma unroll
+    for (int c = 0; c < NB; ++c) {
+      float f[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float b = 0.f;
+        if (MIX) {
+          b = x[i][c];
+        } else {
+          bool have = false;
+#pragma unroll
+          for (int m = 0; m < D1; ++m) {
+            bool nz = false;
+#pragma unroll
+            for (int q = 0; q < D2; ++q) nz |= (C::v[m][q][c] != 0.0);
+            if (nz) {
+              b = have ? __builtin_fmaf(z[m][c], x[i][m], b) : z[m][c] * x[i][m];
+              have = true;
+            }
+          }
+        }
+        f[i] = (i < kleft) ? b : 0.f;
+      }
+      bf16x8 bh, bl;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const __bf16 h = (__bf16)f[i];
+        bh[i] = h;
+        bl[i] = (__bf16)(f[i] - (float)h);
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const bf16x8 wh = __builtin_bit_cast(bf16x8, ah[t]);
+        const bf16x8 wl = __builtin_bit_cast(bf16x8, al[t]);
+        f32x16& dst = MIX ? T[t][c] : acc[t][c];
+        dst = mfma_bf16(wh, bh, dst);
+        dst = mfma_bf16(wh, bl, dst);
+        dst = mfma_bf16(wl, bh, dst);
+      }
+    }
+  };
+  {
+    uint4 ah[NT], al[NT];
+    float x[8][D1];
+    load(0, ah, al, x);
+    for (int kb = 0; kb + 1 < nkb; ++kb) {
+      uint4 ahn[NT], aln[NT];
+      float xn[8][D1];
+      load(kb + 1, ahn, aln, xn);
+      compute(kb, ah, al, x);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) { ah[t] = ahn[t]; al[t] = aln[t]; }
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int m = 0; m < D1; ++m) x[i][m] = xn[i][m];
+    }
+    compute(nkb - 1, ah, al, x);
+  }
+  if (MIX) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int c = 0; c < D3; ++c)
+#pragma unroll
+        for (int a = 0; a < D1; ++a) {
+          bool nz = false;
+#pragma unroll
+          for (int q = 0; q < D2; ++q) nz |= (C::v[a][q][c] != 0.0);
+          if (nz) acc[t][c] += T[t][a] * z[a][c];
+        }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 struct SegArgs {
   const float* base[4];
   int64_t ld[4];
@@ -172,7 +305,7 @@ __device__ __forceinline__ float sigmoid_(float v) { return 1.0f / (1.0f + __exp
 // LSH = SH degree of in2; NT* = number of 32-channel output tiles per degree; L1S... = degrees of the input
 // chunks in order (compile-time so that the chunk walk is straight-line code: no control-flow merges of the
 // 16-register accumulator tuples, which otherwise explode the register allocation).
-template <int LSH, int NT0, int NT1, int NT2, bool WLDS, bool GATE, int... L1S>
+template <int LSH, int NT0, int NT1, int NT2, bool WLDS, bool GATE, bool BF, int... L1S>
 __global__ __launch_bounds__(256) void tp_fwd_mfma_kernel(SegArgs segs, const float* __restrict__ in2, int64_t ld2,
                                                           const float* __restrict__ packed, float* __restrict__ out,
                                                           int64_t ldo, int64_t B, const FDev* __restrict__ dp,
@@ -189,20 +322,29 @@ __global__ __launch_bounds__(256) void tp_fwd_mfma_kernel(SegArgs segs, const fl
 #pragma unroll
   for (int c = 0; c < 3; ++c) { cM[c] = dp->M[c]; cMpad[c] = dp->Mpad[c]; cWoff[c] = dp->woff[c]; cOoff[c] = dp->ooff[c]; }
   const int ntab = dp->ntab;
+  const int bftotal = dp->bftotal;
+  int cBfoff[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) cBfoff[c] = dp->bfoff[c];
+  // weights section of `packed`: [fp32 W' (wtotal) | normcol (Dout) | Whi (bftotal u16) | Wlo (bftotal u16)]
+  const int wwords = BF ? bftotal : wtotal;  // 32-bit words of the weight image this variant keeps in LDS
 
   float* wl = lds;
-  float* nrm = lds + (WLDS ? wtotal : 0);
+  float* nrm = lds + (WLDS ? wwords : 0);
   int* ocl = reinterpret_cast<int*>(nrm + ((Dout + 15) & ~15));
   float* wbase_lds = reinterpret_cast<float*>(ocl + ((ntab + 15) & ~15));
   const int per_wave = nbuf * kChunkFloats + 320;
   float* cbuf = wbase_lds + (size_t)wave * per_wave;
   float* ybuf = cbuf + nbuf * kChunkFloats;
+  const float* wglob = BF ? packed + wtotal + ((Dout + 3) & ~3) : packed;
   if (WLDS)
-    for (int i = tid; i < wtotal; i += blockDim.x) wl[i] = packed[i];
+    for (int i = tid; i < wwords; i += blockDim.x) wl[i] = wglob[i];
   for (int i = tid; i < Dout; i += blockDim.x) nrm[i] = packed[wtotal + i];
   for (int i = tid; i < ntab; i += blockDim.x) ocl[i] = ocol_tab[i];
   __syncthreads();
-  const float* wsrc = WLDS ? wl : packed;
+  const float* wsrc = WLDS ? wl : wglob;
+  const uint4* whi_base = reinterpret_cast<const uint4*>(wsrc);                      // Whi, 8 bf16 per uint4
+  const uint4* wlo_base = reinterpret_cast<const uint4*>(wsrc + (bftotal >> 1));     // Wlo follows Whi
 
   const int64_t ntiles = (B + 31) / 32;
   const int64_t tstride = (int64_t)gridDim.x * nwaves;
@@ -293,8 +435,13 @@ __global__ __launch_bounds__(256) void tp_fwd_mfma_kernel(SegArgs segs, const fl
       const float* xr = xt + j * (cw | 1);
 #define E3_RUN(L2v, L3v, ACC, NTv)                                                                             \
   if constexpr (NTv > 0 && L2v <= LSH && CG<L1, L2v, L3v>::valid && ((L1 + L2v + L3v) % 2 == 0)) {             \
-    const float* wp = wsrc + cWoff[L3v] + (size_t)(ch.wrow[L2v][L3v] + half) * cMpad[L3v] + j;                 \
-    run_steps<L1, L2v, L3v, NTv>(xr, ch.count, wp, cMpad[L3v], half, y, ACC);                                  \
+    if constexpr (BF) {                                                                                        \
+      const size_t o = (size_t)(cBfoff[L3v] >> 3) + (size_t)(2 * ch.wblk[L2v][L3v] + half) * cMpad[L3v] + j;   \
+      run_steps_bf<L1, L2v, L3v, NTv>(xr, ch.count, whi_base + o, wlo_base + o, cMpad[L3v], half, y, ACC);     \
+    } else {                                                                                                   \
+      const float* wp = wsrc + cWoff[L3v] + (size_t)(ch.wrow[L2v][L3v] + half) * cMpad[L3v] + j;               \
+      run_steps<L1, L2v, L3v, NTv>(xr, ch.count, wp, cMpad[L3v], half, y, ACC);                                \
+    }                                                                                                          \
   }
       E3_RUN(0, 0, a0, NT0) E3_RUN(1, 0, a0, NT0) E3_RUN(2, 0, a0, NT0)
       E3_RUN(0, 1, a1, NT1) E3_RUN(1, 1, a1, NT1) E3_RUN(2, 1, a1, NT1)
@@ -436,9 +583,18 @@ __global__ void fast_pack_kernel(const float* w0, const float* w1, const float* 
   for (int r = blockIdx.x; r < npk; r += gridDim.x) {
     const FPack q = pk[r];
     const int M = d.M[q.l3], Mpad = d.Mpad[q.l3];
+    uint16_t* whi = reinterpret_cast<uint16_t*>(packed + d.wtotal + ((d.Dout + 3) & ~3));
+    uint16_t* wlo = whi + d.bftotal;
     for (int i = threadIdx.x; i < q.count * M; i += blockDim.x) {
       int k = i / M, mm = i - k * M;
-      packed[d.woff[q.l3] + (size_t)(q.wrow + k) * Mpad + mm] = w[q.l3][(int64_t)(q.orig_row + k) * M + mm];
+      const float v = w[q.l3][(int64_t)(q.orig_row + k) * M + mm];
+      packed[d.woff[q.l3] + (size_t)(q.wrow + k) * Mpad + mm] = v;
+      // bf16 split, layout [16-row block][k half][channel][8]
+      const __bf16 h = (__bf16)v;
+      const __bf16 l = (__bf16)(v - (float)h);
+      const size_t e = (size_t)d.bfoff[q.l3] + ((size_t)(2 * (q.wblk + (k >> 4)) + ((k >> 3) & 1)) * Mpad + mm) * 8 + (k & 7);
+      whi[e] = __builtin_bit_cast(uint16_t, h);
+      wlo[e] = __builtin_bit_cast(uint16_t, l);
     }
   }
   if (blockIdx.x == 0)
@@ -454,14 +610,18 @@ __global__ void fast_pack_kernel(const float* w0, const float* w1, const float* 
 struct FastKernelEntry {
   int lsh, nt0, nt1, nt2;
   std::vector<int> l1s;
-  const void* fn[2][2];  // [wlds][gate]
+  const void* fn[2][2][2];  // [bf][wlds][gate]
 };
 #define E3_FAST(LSH, a, b, c, ...)                                                                     \
   {LSH, a, b, c, {__VA_ARGS__},                                                                         \
-   {{(const void*)tp_fwd_mfma_kernel<LSH, a, b, c, false, false, __VA_ARGS__>,                          \
-     (const void*)tp_fwd_mfma_kernel<LSH, a, b, c, false, true, __VA_ARGS__>},                          \
-    {(const void*)tp_fwd_mfma_kernel<LSH, a, b, c, true, false, __VA_ARGS__>,                           \
-     (const void*)tp_fwd_mfma_kernel<LSH, a, b, c, true, true, __VA_ARGS__>}}}
+   {{{(const void*)tp_fwd_mfma_kernel<LSH, a, b, c, false, false, false, __VA_ARGS__>,                  \
+      (const void*)tp_fwd_mfma_kernel<LSH, a, b, c, false, true, false, __VA_ARGS__>},                  \
+     {(const void*)tp_fwd_mfma_kernel<LSH, a, b, c, true, false, false, __VA_ARGS__>,                   \
+      (const void*)tp_fwd_mfma_kernel<LSH, a, b, c, true, true, false, __VA_ARGS__>}},                  \
+    {{(const void*)tp_fwd_mfma_kernel<LSH, a, b, c, false, false, true, __VA_ARGS__>,                   \
+      (const void*)tp_fwd_mfma_kernel<LSH, a, b, c, false, true, true, __VA_ARGS__>},                   \
+     {(const void*)tp_fwd_mfma_kernel<LSH, a, b, c, true, false, true, __VA_ARGS__>,                    \
+      (const void*)tp_fwd_mfma_kernel<LSH, a, b, c, true, true, true, __VA_ARGS__>}}}}
 // Instantiated signatures = the tensor products of the SEGNN forward (H <= 32 per block):
 //   l_max 1: embed (0,1 -> hid), msg1 (0,1,0,1,0 -> gated), msg2 (0,1 -> gated), upd1 (0,1,0,1 -> gated),
 //            upd2 (0,1 -> hid), readout (0,1 -> 1o);   l_max 2: the same with (0,1,2) blocks.
@@ -499,7 +659,9 @@ int fast_plan_init(TpFast* F, const int n[6], const int M[6], int lmax_sh, int D
     d.ooff[l3] = ocol_off[cls3[l3]];
   }
   d.lsh = lmax_sh;
+  d.bf = getenv("E3_TP_EXACT") ? 0 : 1;  // default: bf16-split operands (fp32-grade accuracy)
   int next_row[3] = {0, 0, 0};
+  int next_blk[3] = {0, 0, 0};
   int chan_seen[3] = {0, 0, 0};  // channels of in class l1 seen so far
   for (auto& b : in_blocks) {
     const int l1 = b[0], mul = b[2];
@@ -511,6 +673,7 @@ int fast_plan_init(TpFast* F, const int n[6], const int M[6], int lmax_sh, int D
       for (int l2 = 0; l2 < 3; ++l2)
         for (int l3 = 0; l3 < 3; ++l3) {
           ch.wrow[l2][l3] = -1;
+          ch.wblk[l2][l3] = -1;
           if (l2 > lmax_sh || d.M[l3] == 0 || ((l1 + l2 + l3) & 1) || l3 < std::abs(l1 - l2) || l3 > l1 + l2) continue;
           // original row offset of path (l1,l2) in class cls3[l3]
           int orig = -1;
@@ -518,8 +681,10 @@ int fast_plan_init(TpFast* F, const int n[6], const int M[6], int lmax_sh, int D
             if (p.l1 == l1 && p.l2 == l2) orig = p.wrow;
           if (orig < 0) continue;
           ch.wrow[l2][l3] = next_row[l3];
-          F->h_pack.push_back({l3, orig + chan_seen[l1] + 0, ch.count, next_row[l3]});
+          ch.wblk[l2][l3] = next_blk[l3];
+          F->h_pack.push_back({l3, orig + chan_seen[l1] + 0, ch.count, next_row[l3], next_blk[l3]});
           next_row[l3] += (ch.count + 1) & ~1;
+          next_blk[l3] += (ch.count + 15) >> 4;
         }
       chan_seen[l1] += ch.count;
       F->h_chunks.push_back(ch);
@@ -531,6 +696,12 @@ int fast_plan_init(TpFast* F, const int n[6], const int M[6], int lmax_sh, int D
     woff += next_row[l3] * d.Mpad[l3];
   }
   d.wtotal = woff;
+  int bfo = 0;
+  for (int l3 = 0; l3 < 3; ++l3) {
+    d.bfoff[l3] = bfo;
+    bfo += next_blk[l3] * 16 * d.Mpad[l3];
+  }
+  d.bftotal = bfo;
   d.nchunks = (int)F->h_chunks.size();
   if (d.nchunks == 0 || d.wtotal == 0) return E3_OK;
   std::vector<int> l1s;
@@ -538,7 +709,7 @@ int fast_plan_init(TpFast* F, const int n[6], const int M[6], int lmax_sh, int D
   if (!find_fast(lmax_sh, d.NT[0], d.NT[1], d.NT[2], l1s)) return E3_OK;
   // LDS plan
   size_t tables = (size_t)((Dout + 15) & ~15) * 4 + (size_t)((ntab + 15) & ~15) * 4;
-  size_t wbytes = (size_t)d.wtotal * 4;
+  size_t wbytes = d.bf ? (size_t)d.bftotal * 4 : (size_t)d.wtotal * 4;
   auto per_wave = [&](int nbuf) { return (size_t)(nbuf * kChunkFloats + 320) * 4; };
   int nw_w2 = (tables + wbytes + per_wave(2) <= (size_t)kFastLds) ? (int)((kFastLds - tables - wbytes) / per_wave(2)) : 0;
   if (nw_w2 >= 3) { d.w_in_lds = 1; d.nbuf = 2; d.nwaves = std::min(nw_w2, 4); }
@@ -564,9 +735,10 @@ int fast_upload(TpFast* F) {
   E3_HIP_CHECK(hipMalloc((void**)&F->d_dev, sizeof(FDev)));
   E3_HIP_CHECK(hipMemcpy(F->d_dev, &F->dev, sizeof(FDev), hipMemcpyHostToDevice));
   for (auto& e : fast_kernels())
-    for (int a = 0; a < 2; ++a)
-      for (int b = 0; b < 2; ++b)
-        E3_HIP_CHECK(hipFuncSetAttribute(e.fn[a][b], hipFuncAttributeMaxDynamicSharedMemorySize, kFastLds));
+    for (int f = 0; f < 2; ++f)
+      for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 2; ++b)
+          E3_HIP_CHECK(hipFuncSetAttribute(e.fn[f][a][b], hipFuncAttributeMaxDynamicSharedMemorySize, kFastLds));
   return E3_OK;
 }
 
@@ -577,13 +749,15 @@ void fast_free(TpFast* F) {
 }
 
 int64_t fast_packed_bytes(const TpFast* F) {
-  return F->usable ? ((int64_t)(F->dev.wtotal + F->dev.Dout) * 4 + 255) / 256 * 256 : 0;
+  if (!F->usable) return 0;
+  int64_t words = (int64_t)F->dev.wtotal + ((F->dev.Dout + 3) & ~3) + F->dev.bftotal;  // fp32 W' | normcol | Whi+Wlo
+  return (words * 4 + 255) / 256 * 256;
 }
 
 int fast_pack(const TpFast* F, const void* const w[6], const void* const n[6], void* packed, const int32_t* ocol_tab,
               hipStream_t s) {
   if (!F->usable) return E3_OK;
-  E3_HIP_CHECK(hipMemsetAsync(packed, 0, (size_t)F->dev.wtotal * 4, s));
+  E3_HIP_CHECK(hipMemsetAsync(packed, 0, (size_t)fast_packed_bytes(F), s));
   int npk = (int)F->h_pack.size();
   hipLaunchKernelGGL(fast_pack_kernel, dim3(std::max(1, std::min(npk, 256))), dim3(256), 0, s, (const float*)w[0],
                      (const float*)w[3], (const float*)w[4], (const float*)(n ? n[0] : nullptr),
@@ -636,7 +810,7 @@ int fast_forward(const TpFast* F, const e3_tp_segment* segs, int nseg, int D1, c
   const FDev* dd = F->d_dev;
   const FChunk* dc = F->d_chunks;
   void* args[] = {&sa, &in2f, &ld2, &pk, &outf, &ldo, &B, &dd, &dc, &ocol_tab};
-  E3_HIP_CHECK(hipLaunchKernel(e->fn[d.w_in_lds ? 1 : 0][gate ? 1 : 0], dim3(grid), dim3(64 * d.nwaves), args,
+  E3_HIP_CHECK(hipLaunchKernel(e->fn[d.bf ? 1 : 0][d.w_in_lds ? 1 : 0][gate ? 1 : 0], dim3(grid), dim3(64 * d.nwaves), args,
                                F->lds_bytes, s));
   return E3_OK;
 }

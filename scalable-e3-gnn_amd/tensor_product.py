@@ -9,6 +9,7 @@ Forward only (fp32 / fp64), ROCm tensors only, no CPU path.
 from __future__ import annotations
 
 import ctypes
+import os
 from math import sqrt
 
 import torch
@@ -135,7 +136,8 @@ class TPPlan:
                 nb = sum((t.shape[0] * t.shape[1] * 4 + (4 * B if idx is not None else 0)) for t, idx in
                          [(k, s[1]) for k, s in zip(keep, segments)]) + 4 * (self.in2_dim + width) * B
                 profiling.end(f"tp_fused {tag} B={B}", B, nb, t0, flops=self.flops_per_row * B,
-                              kernel="e3::tp_fwd_mfma_kernel")
+                              kernel="e3::tp_fwd_mfma_kernel" + ("<exact fp32 MFMA>" if os.environ.get("E3_TP_EXACT")
+                                                                 else "<bf16x3 split MFMA>"))
         return out
 
 
