@@ -21,6 +21,7 @@ struct FDev {
   int bf;            // 1 = this plan runs the bf16-split kernel
   int bfoff[3];      // element offset (uint16) of class l3 inside Whi (and inside Wlo)
   int bftotal;       // uint16 elements of Whi (== Wlo)
+  int dbg;           // diagnostic build knobs (E3_TP_DBG): 1 = skip output stores, 2 = stage inputs only for the first tile, 4 = skip MFMA runs
 };
 struct FPack { int l3, orig_row, count, wrow, wblk; };
 

@@ -176,7 +176,7 @@ __device__ __forceinline__ void run_steps_bf(const float* __restrict__ xr, const
                                              const int Mpad, const int half, const float (&y)[9],
                                              f32x16 (&acc)[NT][2 * L3 + 1]) {
   constexpr int D1 = 2 * L1 + 1, D2 = 2 * L2 + 1, D3 = 2 * L3 + 1;
-  constexpr bool MIX = D1 < D3;
+  constexpr bool MIX = false;  // bf16 matrix pipe has slack: extra MFMAs are cheaper than folds through the AGPR file
   constexpr int NB = MIX ? D1 : D3;  // B operands per k block
   using C = CG<L1, L2, L3>;
   __builtin_amdgcn_sched_barrier(0);
@@ -216,7 +216,7 @@ __device__ __forceinline__ void run_steps_bf(const float* __restrict__ xr, const
       for (int m = 0; m < D1; ++m) x[i][m] = xp[(16 * kb + i) * D1 + m];
   };
   auto compute = [&](int kb, const uint4 (&ah)[NT], const uint4 (&al)[NT], const float (&x)[8][D1]) {
-    const int kleft = count - (16 * kb + 8 * half);  // channels of this lane's half that are real
+    (void)kb;
 #pragma unroll
     for (int c = 0; c < NB; ++c) {
       float f[8];
@@ -238,7 +238,7 @@ __device__ __forceinline__ void run_steps_bf(const float* __restrict__ xr, const
             }
           }
         }
-        f[i] = (i < kleft) ? b : 0.f;
+        f[i] = b;  // channels beyond `count` were staged as zeros (and their weight rows are zero)
       }
       bf16x8 bh, bl;
 #pragma unroll
@@ -323,6 +323,7 @@ __global__ __launch_bounds__(256) void tp_fwd_mfma_kernel(SegArgs segs, const fl
   for (int c = 0; c < 3; ++c) { cM[c] = dp->M[c]; cMpad[c] = dp->Mpad[c]; cWoff[c] = dp->woff[c]; cOoff[c] = dp->ooff[c]; }
   const int ntab = dp->ntab;
   const int bftotal = dp->bftotal;
+  const int dbg = dp->dbg;
   int cBfoff[3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) cBfoff[c] = dp->bfoff[c];
@@ -355,6 +356,7 @@ __global__ __launch_bounds__(256) void tp_fwd_mfma_kernel(SegArgs segs, const fl
 
     // stage one chunk of 32 rows (LDS-DMA; per-row gather through the segment's row index)
     auto stage = [&](int ci, float* dst) {
+      if ((dbg & 2) && tile != (int64_t)blockIdx.x * nwaves + wave) return;
       const FChunk ch = chunks[ci];
       int s = 0;
       while (s + 1 < segs.nseg && ch.col >= segs.col0[s + 1]) ++s;
@@ -363,15 +365,24 @@ __global__ __launch_bounds__(256) void tp_fwd_mfma_kernel(SegArgs segs, const fl
       const int32_t* idx = segs.index[s];
       const int segcol = ch.col - segs.col0[s];
       const int cw = ch.count * (2 * ch.l1 + 1);
-      const int stride = cw | 1;
+      const int cwp = BF ? ((ch.count + 15) & ~15) * (2 * ch.l1 + 1) : cw;  // bf16 variant: zero-pad to 16 channels
+      const int stride = cwp | 1;
       int64_t myrow = row0 + j;
       if (idx && j < nrows) myrow = idx[row0 + j];
       const int mr = (int)myrow;  // row ids fit int32 (N, E < 2^31)
-      if (cw == 1) {
-        if (lane < nrows)
-          __builtin_amdgcn_global_load_lds((glb_void_t*)(base + (int64_t)mr * ld + segcol), (lds_void_t*)dst, 4, 0, 0);
-        else if (lane < 32)
-          dst[lane] = 0.f;
+      if (cwp > cw) {  // zero the padding columns (small chunks only, e.g. the distance scalar)
+        for (int r = 0; r < 32; ++r)
+          for (int dc = cw + lane; dc < cwp; dc += 64) dst[r * stride + dc] = 0.f;
+      }
+      if (cw == 1) {  // one column (the distance scalar): lane r fetches row r
+        if (stride == 1) {
+          if (lane < nrows)
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(base + (int64_t)mr * ld + segcol), (lds_void_t*)dst, 4, 0, 0);
+          else if (lane < 32)
+            dst[lane] = 0.f;
+        } else if (lane < 32) {  // padded rows are not contiguous: the DMA cannot scatter, use a register load
+          dst[lane * stride] = (lane < nrows) ? base[(int64_t)mr * ld + segcol] : 0.f;
+        }
         return;
       }
       const int full = cw & ~63;
@@ -431,11 +442,12 @@ __global__ __launch_bounds__(256) void tp_fwd_mfma_kernel(SegArgs segs, const fl
       const float* xt = cbuf + cur * kChunkFloats;
       if (nbuf == 2 && ci + 1 < nchunks) stage(ci + 1, cbuf + (cur ^ 1) * kChunkFloats);
       const FChunk ch = chunks[ci];
-      const int cw = ch.count * (2 * L1 + 1);
-      const float* xr = xt + j * (cw | 1);
+      const int cwp = (BF ? ((ch.count + 15) & ~15) : ch.count) * (2 * L1 + 1);
+      const float* xr = xt + j * (cwp | 1);
 #define E3_RUN(L2v, L3v, ACC, NTv)                                                                             \
   if constexpr (NTv > 0 && L2v <= LSH && CG<L1, L2v, L3v>::valid && ((L1 + L2v + L3v) % 2 == 0)) {             \
-    if constexpr (BF) {                                                                                        \
+    if (dbg & 4) {                                                                                             \
+    } else if constexpr (BF) {                                                                                        \
       const size_t o = (size_t)(cBfoff[L3v] >> 3) + (size_t)(2 * ch.wblk[L2v][L3v] + half) * cMpad[L3v] + j;   \
       run_steps_bf<L1, L2v, L3v, NTv>(xr, ch.count, whi_base + o, wlo_base + o, cMpad[L3v], half, y, ACC);     \
     } else {                                                                                                   \
@@ -476,7 +488,7 @@ __global__ __launch_bounds__(256) void tp_fwd_mfma_kernel(SegArgs segs, const fl
         const int lc = lane & 31, rs = lane >> 5;
         uint32_t off = (uint32_t)lc + rs * ldo32;
         const float* src = ot + rs * 33 + lc;
-        for (int r = rs; r < nrows; r += 2) { obase[off] = *src; off += 2 * ldo32; src += 2 * 33; }
+        for (int r = rs; r < nrows; r += 2) { if (!(dbg & 1)) obase[off] = *src; off += 2 * ldo32; src += 2 * 33; }
       }
       wave_sync_lds();
       int ocol = 32;
@@ -493,7 +505,7 @@ __global__ __launch_bounds__(256) void tp_fwd_mfma_kernel(SegArgs segs, const fl
         for (int lc = lane; lc < 96; lc += 64) {
           uint32_t off = (uint32_t)(ocol + lc);
           const float* src = ot + lc;
-          for (int r = 0; r < nrows; ++r) { obase[off] = *src; off += ldo32; src += 97; }
+          for (int r = 0; r < nrows; ++r) { if (!(dbg & 1)) obase[off] = *src; off += ldo32; src += 97; }
         }
         wave_sync_lds();
         ocol += 96;
@@ -512,7 +524,7 @@ __global__ __launch_bounds__(256) void tp_fwd_mfma_kernel(SegArgs segs, const fl
         for (int lc = lane; lc < 160; lc += 64) {
           uint32_t off = (uint32_t)(ocol + lc);
           const float* src = ot + lc;
-          for (int r = 0; r < nrows; ++r) { obase[off] = *src; off += ldo32; src += 161; }
+          for (int r = 0; r < nrows; ++r) { if (!(dbg & 1)) obase[off] = *src; off += ldo32; src += 161; }
         }
         wave_sync_lds();
       }
@@ -528,7 +540,7 @@ __global__ __launch_bounds__(256) void tp_fwd_mfma_kernel(SegArgs segs, const fl
           const float nm = nrm[col];
           uint32_t off = (uint32_t)col + rs * ldo32;
           const float* src = ot + rs * 33 + lc;
-          for (int r = rs; r < nrows; r += 2) { obase[off] = *src * nm; off += 2 * ldo32; src += 2 * 33; }
+          for (int r = rs; r < nrows; r += 2) { if (!(dbg & 1)) obase[off] = *src * nm; off += 2 * ldo32; src += 2 * 33; }
         }
         wave_sync_lds();
       }
@@ -546,7 +558,7 @@ __global__ __launch_bounds__(256) void tp_fwd_mfma_kernel(SegArgs segs, const fl
           const float nm = nrm[col];
           uint32_t off = (uint32_t)col;
           const float* src = ot + lc;
-          for (int r = 0; r < nrows; ++r) { obase[off] = *src * nm; off += ldo32; src += 97; }
+          for (int r = 0; r < nrows; ++r) { if (!(dbg & 1)) obase[off] = *src * nm; off += ldo32; src += 97; }
         }
         wave_sync_lds();
       }
@@ -564,7 +576,7 @@ __global__ __launch_bounds__(256) void tp_fwd_mfma_kernel(SegArgs segs, const fl
           const float nm = nrm[col];
           uint32_t off = (uint32_t)col;
           const float* src = ot + lc;
-          for (int r = 0; r < nrows; ++r) { obase[off] = *src * nm; off += ldo32; src += 161; }
+          for (int r = 0; r < nrows; ++r) { if (!(dbg & 1)) obase[off] = *src * nm; off += ldo32; src += 161; }
         }
         wave_sync_lds();
       }
@@ -659,7 +671,8 @@ int fast_plan_init(TpFast* F, const int n[6], const int M[6], int lmax_sh, int D
     d.ooff[l3] = ocol_off[cls3[l3]];
   }
   d.lsh = lmax_sh;
-  d.bf = getenv("E3_TP_EXACT") ? 0 : 1;  // default: bf16-split operands (fp32-grade accuracy)
+  d.bf = getenv("E3_TP_EXACT") ? 0 : 1;
+  d.dbg = getenv("E3_TP_DBG") ? atoi(getenv("E3_TP_DBG")) : 0;  // timing-only diagnostics, results are wrong when set  // default: bf16-split operands (fp32-grade accuracy)
   int next_row[3] = {0, 0, 0};
   int next_blk[3] = {0, 0, 0};
   int chan_seen[3] = {0, 0, 0};  // channels of in class l1 seen so far
