@@ -210,7 +210,7 @@ int e3_tp_norm_len(const e3_tp_plan* plan, int cls);
 int64_t e3_tp_packed_bytes(const e3_tp_plan* plan, int dtype);
 int e3_tp_pack_weights(const e3_tp_plan* plan, const void* const weights[6], const void* const norms[6],
                        int dtype, void* packed, void* stream);
-/* dtype E3_F32 or E3_F64; ld_in2 == 0 broadcasts row 0 of in2 */
+/* dtype E3_F32 / E3_F64 (in2 of the same type; ld_in2 == 0 broadcasts row 0) or E3_BF16 (in2 fp32, see below) */
 int e3_tp_forward(const e3_tp_plan* plan, const void* in1, int64_t ld_in1, const void* in2, int64_t ld_in2,
                   const void* packed, void* out, int64_t ld_out, int64_t B, int dtype, void* stream);
 /*
@@ -226,6 +226,13 @@ int e3_tp_forward_fused(const e3_tp_plan* plan, const e3_tp_segment* segs, int n
                         const void* in2, int64_t ld_in2, const void* packed, void* out, int64_t ld_out,
                         int64_t B, int dtype, int gate, void* stream);
 int e3_tp_fused_supported(const e3_tp_plan* plan, int gate);
+/*
+ * bf16 storage (dtype E3_BF16, BASELINE config 3): segments / in1 / out / weights / norms are bf16, in2 (the
+ * spherical harmonics) stays fp32, products run once on v_mfma_f32_32x32x16_bf16 with fp32 accumulation and one
+ * rounding of the result.  Only the MFMA path exists for bf16 (E3_ERR_UNSUPPORTED otherwise).
+ */
+int e3_segment_sum_bf16(const void* msg, int64_t ld_msg, const int32_t* rowptr, int64_t N, int D,
+                        void* agg, int64_t ld_agg, void* stream);
 /* SH / geometry for lmax 2: edge_y [E,9], node_a [N,9] (same definitions as e3_edge_geometry, Y2 = sqrt5 b(r^)) */
 int e3_edge_geometry_l2(const float* pos4, const int32_t* rowptr, const int32_t* src, int64_t N,
                         float* edge_y, float* edge_d, float* node_a, void* stream);

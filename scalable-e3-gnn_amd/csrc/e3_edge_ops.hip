@@ -197,6 +197,28 @@ __global__ __launch_bounds__(256) void gate_blocks_kernel(const float* __restric
   }
 }
 
+// bf16 storage variant: fp32 accumulation, one rounding at the end
+__global__ __launch_bounds__(256) void segment_sum_bf16_kernel(const bf16* __restrict__ msg, int64_t ld_msg,
+                                                               const int32_t* __restrict__ rowptr, int64_t N, int D,
+                                                               bf16* __restrict__ agg, int64_t ld_agg) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t i = wave0; i < N; i += nw) {
+    const int b = rowptr[i], e = rowptr[i + 1];
+    for (int c = lane; c < D; c += 64) {
+      float acc = 0.f;
+      const bf16* m = msg + (int64_t)b * ld_msg + c;
+#pragma unroll 4
+      for (int q = b; q < e; ++q) {
+        acc += __bfloat162float(*m);
+        m += ld_msg;
+      }
+      agg[i * ld_agg + c] = __float2bfloat16(acc);
+    }
+  }
+}
+
 static inline int wave_grid(int64_t N) { return (int)std::max<int64_t>(1, std::min<int64_t>((N + 3) / 4, 256 * 16)); }
 
 }  // namespace e3
@@ -245,6 +267,17 @@ int e3_segment_sum(const float* msg, int64_t ld_msg, const int32_t* rowptr, int6
   if (!msg || !rowptr || !agg) return E3_ERR_INVALID_ARG;
   hipLaunchKernelGGL(segment_sum_kernel, dim3(wave_grid(N)), dim3(256), 0, (hipStream_t)stream, msg, ld_msg, rowptr, N,
                      D, agg, ld_agg);
+  E3_HIP_CHECK(hipGetLastError());
+  return E3_OK;
+}
+
+int e3_segment_sum_bf16(const void* msg, int64_t ld_msg, const int32_t* rowptr, int64_t N, int D, void* agg,
+                        int64_t ld_agg, void* stream) {
+  if (N < 0 || D <= 0 || ld_msg < D || ld_agg < D) return E3_ERR_INVALID_ARG;
+  if (N == 0) return E3_OK;
+  if (!msg || !rowptr || !agg) return E3_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(segment_sum_bf16_kernel, dim3(wave_grid(N)), dim3(256), 0, (hipStream_t)stream, (const bf16*)msg,
+                     ld_msg, rowptr, N, D, (bf16*)agg, ld_agg);
   E3_HIP_CHECK(hipGetLastError());
   return E3_OK;
 }

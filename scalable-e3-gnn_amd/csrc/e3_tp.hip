@@ -293,16 +293,16 @@ int e3_tp_norm_len(const e3_tp_plan* p, int cls) {
   return (p && cls >= 0 && cls < 6) ? p->dev.M[cls] * (2 * (cls >> 1) + 1) : -1;
 }
 int64_t e3_tp_packed_bytes(const e3_tp_plan* p, int dtype) {
-  if (!p || (dtype != E3_F32 && dtype != E3_F64)) return -1;
+  if (!p || dtype < 0 || dtype > 2) return -1;
   int64_t b = ((p->dev.packed_elems + 64) * (dtype == E3_F64 ? 8 : 4) + 255) / 256 * 256;
-  if (dtype == E3_F32) b += fast_packed_bytes(&p->fast);
+  if (dtype != E3_F64) b += fast_packed_bytes(&p->fast);
   return b;
 }
 static inline int64_t fast_section_offset(const e3_tp_plan* p) { return ((p->dev.packed_elems + 64) * 4 + 255) / 256 * 256; }
 
 int e3_tp_pack_weights(const e3_tp_plan* plan, const void* const w[6], const void* const n[6], int dtype, void* packed,
                        void* stream) {
-  if (!plan || !w || !packed || (dtype != E3_F32 && dtype != E3_F64)) return E3_ERR_INVALID_ARG;
+  if (!plan || !w || !packed || dtype < 0 || dtype > 2) return E3_ERR_INVALID_ARG;
   for (int c = 0; c < 6; ++c)
     if (plan->dev.M[c] > 0 && plan->dev.K[c] > 0 && !w[c]) return E3_ERR_MISSING_WEIGHT;
   int st = tp_ensure_device(plan);
@@ -316,31 +316,37 @@ int e3_tp_pack_weights(const e3_tp_plan* plan, const void* const w[6], const voi
                        (const float*)w[2], (const float*)w[3], (const float*)w[4], (const float*)w[5],
                        (const float*)nn[0], (const float*)nn[1], (const float*)nn[2], (const float*)nn[3],
                        (const float*)nn[4], (const float*)nn[5], (float*)packed, plan->dev);
+  else if (dtype == E3_BF16)
+    hipLaunchKernelGGL(tp_pack_kernel<bf16>, dim3(64), dim3(256), 0, s, (const bf16*)w[0], (const bf16*)w[1],
+                       (const bf16*)w[2], (const bf16*)w[3], (const bf16*)w[4], (const bf16*)w[5], (const bf16*)nn[0],
+                       (const bf16*)nn[1], (const bf16*)nn[2], (const bf16*)nn[3], (const bf16*)nn[4],
+                       (const bf16*)nn[5], (float*)packed, plan->dev);
   else
     hipLaunchKernelGGL(tp_pack_kernel<double>, dim3(64), dim3(256), 0, s, (const double*)w[0], (const double*)w[1],
                        (const double*)w[2], (const double*)w[3], (const double*)w[4], (const double*)w[5],
                        (const double*)nn[0], (const double*)nn[1], (const double*)nn[2], (const double*)nn[3],
                        (const double*)nn[4], (const double*)nn[5], (double*)packed, plan->dev);
   E3_HIP_CHECK(hipGetLastError());
-  if (dtype == E3_F32 && plan->fast.usable)
-    return fast_pack(&plan->fast, w, nn, (char*)packed + fast_section_offset(plan), plan->dev.ocol, s);
+  if (dtype != E3_F64 && plan->fast.usable)
+    return fast_pack(&plan->fast, w, nn, dtype, (char*)packed + fast_section_offset(plan), plan->dev.ocol, s);
   return E3_OK;
 }
 
 int e3_tp_forward(const e3_tp_plan* plan, const void* in1, int64_t ld1, const void* in2, int64_t ld2,
                   const void* packed, void* out, int64_t ldo, int64_t B, int dtype, void* stream) {
-  if (!plan || B < 0 || (dtype != E3_F32 && dtype != E3_F64)) return E3_ERR_INVALID_ARG;
+  if (!plan || B < 0 || dtype < 0 || dtype > 2) return E3_ERR_INVALID_ARG;
   if (B == 0) return E3_OK;
   if (!in1 || !in2 || !packed || !out) return E3_ERR_INVALID_ARG;
+  if (dtype == E3_BF16 && (!plan->fast.usable || ld2 == 0)) return E3_ERR_UNSUPPORTED;  // bf16 storage: MFMA path only
   if (ld1 < plan->dev.D1 || ldo < plan->dev.Dout || (ld2 != 0 && ld2 < plan->dev.Dy)) return E3_ERR_INVALID_ARG;
   int st = tp_ensure_device(plan);
   if (st != E3_OK) return st;
   hipStream_t s = (hipStream_t)stream;
   static const bool no_fast = getenv("E3_TP_GENERIC") != nullptr;
-  if (dtype == E3_F32 && plan->fast.usable && ld2 != 0 && !no_fast) {
+  if (dtype != E3_F64 && plan->fast.usable && ld2 != 0 && (!no_fast || dtype == E3_BF16)) {
     e3_tp_segment seg = {in1, ld1, nullptr, plan->dev.D1, 0};
     return fast_forward(&plan->fast, &seg, 1, plan->dev.D1, in2, ld2, (const char*)packed + fast_section_offset(plan),
-                        out, ldo, B, 0, plan->dev.ocol, s);
+                        out, ldo, B, 0, dtype, plan->dev.ocol, s);
   }
   return dtype == E3_F32 ? tp_launch_fwd<float>(plan, in1, ld1, in2, ld2, packed, out, ldo, B, s)
                          : tp_launch_fwd<double>(plan, in1, ld1, in2, ld2, packed, out, ldo, B, s);
@@ -349,13 +355,13 @@ int e3_tp_forward(const e3_tp_plan* plan, const void* in1, int64_t ld1, const vo
 int e3_tp_forward_fused(const e3_tp_plan* plan, const e3_tp_segment* segs, int nseg, const void* in2, int64_t ld2,
                         const void* packed, void* out, int64_t ldo, int64_t B, int dtype, int gate, void* stream) {
   if (!plan || !segs || B < 0) return E3_ERR_INVALID_ARG;
-  if (dtype != E3_F32 || !plan->fast.usable || ld2 == 0) return E3_ERR_UNSUPPORTED;
+  if ((dtype != E3_F32 && dtype != E3_BF16) || !plan->fast.usable || ld2 == 0) return E3_ERR_UNSUPPORTED;
   if (B == 0) return E3_OK;
   if (!in2 || !packed || !out || ld2 < plan->dev.Dy) return E3_ERR_INVALID_ARG;
   int st = tp_ensure_device(plan);
   if (st != E3_OK) return st;
   return fast_forward(&plan->fast, segs, nseg, plan->dev.D1, in2, ld2, (const char*)packed + fast_section_offset(plan),
-                      out, ldo, B, gate, plan->dev.ocol, (hipStream_t)stream);
+                      out, ldo, B, gate, dtype, plan->dev.ocol, (hipStream_t)stream);
 }
 
 int e3_tp_fused_supported(const e3_tp_plan* plan, int gate) {

@@ -18,7 +18,7 @@ struct FDev {
   int Dout, Dy, nchunks, nwaves, nbuf, w_in_lds, wtotal, ntab, lsh;
   int M[3], NT[3], Mpad[3], woff[3], ooff[3];  // per output degree l3 (classes 0e, 1o, 2e)
   // bf16-split variant (BF): weights as hi/lo bf16 in [16-row block][k half][channel][8] order
-  int bf;            // 1 = this plan runs the bf16-split kernel
+  int bf;            // fp32-storage mode: 1 = bf16x3-split kernel, 0 = exact fp32 MFMA kernel
   int bfoff[3];      // element offset (uint16) of class l3 inside Whi (and inside Wlo)
   int bftotal;       // uint16 elements of Whi (== Wlo)
   int dbg;           // diagnostic build knobs (E3_TP_DBG): 1 = skip output stores, 2 = stage inputs only for the first tile, 4 = skip MFMA runs
@@ -26,7 +26,10 @@ struct FDev {
 struct FPack { int l3, orig_row, count, wrow, wblk; };
 
 struct TpFast {
-  FDev dev;
+  FDev dev;    // plan for fp32 storage (exact or bf16x3-split operands)
+  FDev dev16;  // plan for bf16 storage (smaller chunk buffers, hi-only weights): differs in nwaves/nbuf/w_in_lds
+  FDev* d_dev16 = nullptr;
+  size_t lds_bytes16 = 0;
   std::vector<FChunk> h_chunks;
   std::vector<FPack> h_pack;
   FChunk* d_chunks = nullptr;
@@ -42,10 +45,10 @@ int fast_plan_init(TpFast* F, const int n[6], const int M[6], int lmax_sh, int D
 int fast_upload(TpFast* F);
 void fast_free(TpFast* F);
 int64_t fast_packed_bytes(const TpFast* F);
-int fast_pack(const TpFast* F, const void* const w[6], const void* const n[6], void* packed, const int32_t* ocol_tab,
-              hipStream_t s);
+int fast_pack(const TpFast* F, const void* const w[6], const void* const n[6], int dtype, void* packed,
+              const int32_t* ocol_tab, hipStream_t s);
 int fast_forward(const TpFast* F, const e3_tp_segment* segs, int nseg, int D1, const void* in2, int64_t ld2,
-                 const void* packed, void* out, int64_t ldo, int64_t B, int gate, const int32_t* ocol_tab,
+                 const void* packed, void* out, int64_t ldo, int64_t B, int gate, int dtype, const int32_t* ocol_tab,
                  hipStream_t s);
 
 }  // namespace e3

@@ -72,16 +72,20 @@ def gate(x: torch.Tensor, ns: int, nv: int) -> torch.Tensor:
 
 
 def segment_sum(msg: torch.Tensor, g: RadiusGraph) -> torch.Tensor:
-    """agg[i] = sum of msg rows of CSR row i (fixed order, reproducible)"""
-    _check(msg, "msg")
+    """agg[i] = sum of msg rows of CSR row i (fixed order, reproducible); fp32, or bf16 storage with fp32 accumulation"""
+    if not msg.is_cuda:
+        raise RuntimeError("msg: ROCm tensor required (no CPU path)")
+    if msg.dtype not in (torch.float32, torch.bfloat16):
+        raise RuntimeError(f"segment_sum: float32 / bfloat16 required, got {msg.dtype}")
     if msg.stride(-1) != 1:
         msg = msg.contiguous()
     N = g.rowptr.numel() - 1
     D = msg.shape[1]
-    agg = torch.empty((N, D), dtype=torch.float32, device=msg.device)
+    agg = torch.empty((N, D), dtype=msg.dtype, device=msg.device)
+    fn = "e3_segment_sum" if msg.dtype == torch.float32 else "e3_segment_sum_bf16"
     with torch.cuda.device(msg.device):
-        _lib.check(_lib.load().e3_segment_sum(msg.data_ptr(), msg.stride(0), g.rowptr.data_ptr(), N, D,
-                                              agg.data_ptr(), agg.stride(0), _stream(msg)), "e3_segment_sum")
+        _lib.check(getattr(_lib.load(), fn)(msg.data_ptr(), msg.stride(0), g.rowptr.data_ptr(), N, D,
+                                            agg.data_ptr(), agg.stride(0), _stream(msg)), fn)
     return agg
 
 

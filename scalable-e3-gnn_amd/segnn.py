@@ -66,8 +66,12 @@ class SEGNNLayer(nn.Module):
         return f and not torch.is_grad_enabled()
 
     def forward(self, h, g: RadiusGraph, Y, d, A):
+        if h.dtype == torch.bfloat16 and not (self.fused and self._fused()):
+            raise RuntimeError("bf16 storage needs the fused MFMA path (H = 32, torch.no_grad())")
         if self.fused and self._fused():
             # gather + concat + TP + gate in one kernel each: no [E, 2D+1] / raw-TP tensors in HBM
+            if d.dtype != h.dtype:
+                d = d.to(h.dtype)
             m = self.msg1.forward_fused([(h, g.dst), (h, g.src), (d, None)], Y, gate=True)
             m = self.msg2.forward_fused([(m, None)], Y, gate=True)
             a = ops.segment_sum(m, g)
@@ -101,6 +105,8 @@ class SEGNN(nn.Module):
         refreshed from their owners before every message-passing layer; only owned rows of the result
         are meaningful."""
         Y, d, A = geometry if geometry is not None else ops.edge_geometry(g, lmax=self.lmax)
+        if x.dtype == torch.bfloat16 and self.lmax != 2:
+            raise RuntimeError("bf16 storage is implemented for l_max = 2 (BASELINE config 3)")
         h = self.embed(x, A)
         for layer in self.layers:
             if halo is not None:

@@ -99,9 +99,14 @@ class TPPlan:
         dev = in2.device
         segs = (TPSegment * len(segments))()
         keep = []
+        io = segments[0][0].dtype
+        if io not in (torch.float32, torch.bfloat16):
+            raise RuntimeError(f"forward_fused: float32 / bfloat16 storage only, got {io}")
+        if in2.dtype != torch.float32:
+            raise RuntimeError("forward_fused: in2 (spherical harmonics) is always float32")
         for i, (t, idx) in enumerate(segments):
-            if t.dtype != torch.float32 or not t.is_cuda:
-                raise RuntimeError("forward_fused: float32 ROCm tensors required")
+            if t.dtype != io or not t.is_cuda:
+                raise RuntimeError("forward_fused: all segments must share one dtype and live on a ROCm device")
             if t.dim() == 1:
                 t = t.unsqueeze(1)
             if t.stride(-1) != 1:
@@ -119,25 +124,27 @@ class TPPlan:
             width = {160: 128, 352: 288, 224: 192}.get(self.out_dim)
             if width is None:
                 raise RuntimeError("gate fusion needs out irreps [32x0e | 32x0e per block | 32x1o | 32x2e]")
-        out = torch.empty((B, width), dtype=torch.float32, device=dev)
+        out = torch.empty((B, width), dtype=io, device=dev)
         if B == 0:
             return out
         if in2.stride(-1) != 1:
             in2 = in2.contiguous()
+        esz = out.element_size()
         with torch.cuda.device(dev):
-            packed = self.packed(ws, ns, torch.float32, dev)
+            packed = self.packed(ws, ns, io, dev)
             stream = torch.cuda.current_stream(dev).cuda_stream
             t0 = profiling.begin() if profiling.enabled() else None
             _lib.check(lib.e3_tp_forward_fused(self.handle, ctypes.byref(segs), len(segments), in2.data_ptr(),
                                                in2.stride(0), packed.data_ptr(), out.data_ptr(), out.stride(0), B,
-                                               _lib.E3_F32, 1 if gate else 0, stream), "e3_tp_forward_fused")
+                                               _lib.dtype_code(io), 1 if gate else 0, stream), "e3_tp_forward_fused")
             if t0 is not None:
                 # algorithmic bytes: gathered segments count their SOURCE rows once (re-gathers are cache traffic)
-                nb = sum((t.shape[0] * t.shape[1] * 4 + (4 * B if idx is not None else 0)) for t, idx in
-                         [(k, s[1]) for k, s in zip(keep, segments)]) + 4 * (self.in2_dim + width) * B
+                nb = sum((t.shape[0] * t.shape[1] * esz + (4 * B if idx is not None else 0)) for t, idx in
+                         [(k, s[1]) for k, s in zip(keep, segments)]) + (4 * self.in2_dim + esz * width) * B
+                mode = ("<bf16 storage, bf16 MFMA>" if io == torch.bfloat16 else
+                        "<exact fp32 MFMA>" if os.environ.get("E3_TP_EXACT") else "<bf16x3 split MFMA>")
                 profiling.end(f"tp_fused {tag} B={B}", B, nb, t0, flops=self.flops_per_row * B,
-                              kernel="e3::tp_fwd_mfma_kernel" + ("<exact fp32 MFMA>" if os.environ.get("E3_TP_EXACT")
-                                                                 else "<bf16x3 split MFMA>"))
+                              kernel="e3::tp_fwd_mfma_kernel" + mode)
         return out
 
 
@@ -192,6 +199,9 @@ class SHTensorProduct(nn.Module):
         out = torch.empty((B, self.out_dim), dtype=in1.dtype, device=in1.device)
         if B == 0:
             return out
+        want2 = torch.float32 if in1.dtype == torch.bfloat16 else in1.dtype  # bf16 storage keeps the SH in fp32
+        if in2.dtype != want2:
+            raise RuntimeError(f"SHTensorProduct: in2 must be {want2} for in1 {in1.dtype}, got {in2.dtype}")
         if in1.stride(-1) != 1:
             in1 = in1.contiguous()
         if in2.stride(-1) != 1:
@@ -209,6 +219,6 @@ class SHTensorProduct(nn.Module):
                 profiling.end(f"tp_fwd(l<=2) {self.iri1}->{self.iro} B={B}", B,
                               in1.element_size() * (self.in1_dim + self.in2_dim + self.out_dim) * B, t0,
                               flops=self._plan.flops_per_row * B,
-                              kernel="e3::tp_fwd_mfma_kernel" if (in1.dtype == torch.float32 and
+                              kernel="e3::tp_fwd_mfma_kernel" if (in1.dtype != torch.float64 and
                                                                    self._plan.fused_supported(False)) else "e3::tp_fwd_generic_kernel")
         return out
