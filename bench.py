@@ -52,7 +52,7 @@ def cpu_baseline(args, state):
     pos = torch.rand(n, 3, generator=g).numpy()
     x = torch.randn(n, 4, generator=torch.Generator().manual_seed(1)).numpy()
     r = cutoff(n)
-    params = {k: v.detach().float().cpu().numpy() for k, v in state.items()}
+    params = {k: v.detach().float().cpu().numpy() for k, v in state.items()}  # CPU baseline always runs in fp32
     fwd = S.forward_torch_cpu if args.lmax == 1 else S.forward_l2_torch_cpu
     best = None
     for _ in range(1):
@@ -78,6 +78,8 @@ def main():
     ap.add_argument("--layers", type=int, default=4)
     ap.add_argument("--lmax", type=int, default=2, help="2 = the configuration BASELINE.json's metric is quoted on")
     ap.add_argument("--cpu-sample", type=int, default=None, help="particles in the CPU-baseline sample")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="storage type of features / weights (bf16 = BASELINE config 3; l_max=2 only)")
     ap.add_argument("--timing-json", type=str, default=None, help="also dump per-TP timings here")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -123,6 +125,11 @@ def main():
     r = cutoff(n)
     torch.manual_seed(0)
     model = SEGNN("1x0e+1x1o", args.hidden, "1x1o", args.layers, lmax=args.lmax).to(dev)
+    if args.dtype == "bf16":
+        if args.lmax != 2:
+            raise SystemExit("--dtype bf16 is implemented for --lmax 2")
+        model = model.bfloat16()
+        x = x.bfloat16()
     halo = None
     if world > 1:
         from scalable_e3_gnn_amd.sharding import SlabHalo
@@ -177,7 +184,8 @@ def main():
         # bf16x3 split kernel: every fp32 product is executed as 3 bf16 MFMA products (hi*hi + hi*lo + lo*hi) -> the
         # matrix pipe sees 3x the algorithmic flops and its peak is the bf16 dense peak
         split = "bf16x3" in dom["kernel"]
-        mfma_peak = MFMA_BF16_PEAK_TF if split else MFMA_F32_PEAK_TF
+        native16 = "bf16 storage" in dom["kernel"]
+        mfma_peak = MFMA_BF16_PEAK_TF if (split or native16) else MFMA_F32_PEAK_TF
         exec_mult = 3.0 if split else 1.0
         mfma_bound = dom["flops_per_launch"] * exec_mult / (mfma_peak * 1e12) > dom["bytes_per_launch"] / (HBM_PEAK_GBS * 1e9)
         traffic = None
@@ -188,7 +196,8 @@ def main():
                 "achieved": tfs * exec_mult if mfma_bound else gbs, "peak": mfma_peak if mfma_bound else HBM_PEAK_GBS,
                 "unit": "TFLOP/s" if mfma_bound else "GB/s",
                 "frac": (tfs * exec_mult / mfma_peak) if mfma_bound else (gbs / HBM_PEAK_GBS), "traffic": traffic,
-                "mfma_mode": "bf16x3 split (3 bf16 MFMA products per fp32 product, fp32 accumulate)" if split else "fp32",
+                "mfma_mode": ("bf16x3 split (3 bf16 MFMA products per fp32 product, fp32 accumulate)" if split else
+                              "bf16 operands, fp32 accumulate" if native16 else "fp32"),
                 "fp32_equivalent_TFLOPps": tfs, "fp32_equivalent_frac_of_157.3": tfs / MFMA_F32_PEAK_TF,
                 "avg_launch_ms": dom["avg_ms"], "launches": dom["launches"],
                 "algorithmic_bytes_per_launch": dom["bytes_per_launch"],
@@ -200,12 +209,14 @@ def main():
         line = {
             "metric": METRIC, "value": total_particles / (dt / args.steps), "unit": "particles/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "numerics": "fp32 storage and accumulation; tensor-product contractions as bf16x3-split MFMA "
-                        "(measured 4e-6 rms relative error vs fp64, bar 1e-5; E3_TP_EXACT=1 selects exact fp32 MFMA)",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "numerics": ("fp32 storage and accumulation; tensor-product contractions as bf16x3-split MFMA "
+                         "(measured 4e-6 rms relative error vs fp64, bar 1e-5; E3_TP_EXACT=1 selects exact fp32 MFMA)")
+                        if args.dtype == "f32" else
+                        ("bf16 storage of features/weights/messages, fp32 spherical harmonics, bf16 MFMA with fp32 "
+                         "accumulation (one TP within 1e-2 of the fp64 oracle on bf16-rounded inputs)"),
             "config": {"workload": f"{n} particles/GPU uniform in unit box, radius graph k~24 (E={g.num_edges}), "
-                                   f"SEGNN l_max={args.lmax} {args.layers} layers H={args.hidden} fp32 (BASELINE config 3 names bf16 storage: "
-                                   f"not built, fp32 throughout)",
+                                   f"SEGNN l_max={args.lmax} {args.layers} layers H={args.hidden} {args.dtype} storage",
                        "particles_per_gpu": n, "edges_per_gpu": g.num_edges, "hidden": args.hidden,
                        "layers": args.layers, "lmax": args.lmax,
                        "parallelism": (f"spatial slabs x{world}, ghost halo width r, 1 position + {args.layers} feature "

@@ -226,6 +226,10 @@ int e3_tp_forward_fused(const e3_tp_plan* plan, const e3_tp_segment* segs, int n
                         const void* in2, int64_t ld_in2, const void* packed, void* out, int64_t ld_out,
                         int64_t B, int dtype, int gate, void* stream);
 int e3_tp_fused_supported(const e3_tp_plan* plan, int gate);
+/* diagnostic (E3_TP_DBG & 8 at plan creation): wave-cycle sums per kernel phase since the last call:
+ * [0] tile prologue issue, [1] waiting for staged data, [2] staging issue, [3] MFMA runs, [4] epilogue: gate +
+ * transpose into LDS, [5] epilogue: norm + stores, [6..7] unused */
+int e3_tp_debug_phase_cycles(const e3_tp_plan* plan, unsigned long long out[8]);
 /*
  * bf16 storage (dtype E3_BF16, BASELINE config 3): segments / in1 / out / weights / norms are bf16, in2 (the
  * spherical harmonics) stays fp32, products run once on v_mfma_f32_32x32x16_bf16 with fp32 accumulation and one

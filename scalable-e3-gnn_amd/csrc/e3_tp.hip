@@ -364,6 +364,17 @@ int e3_tp_forward_fused(const e3_tp_plan* plan, const e3_tp_segment* segs, int n
                       out, ldo, B, gate, dtype, plan->dev.ocol, (hipStream_t)stream);
 }
 
+// diagnostic: per-phase wave-cycle sums of the MFMA kernel (E3_TP_DBG & 8); reads and clears
+int e3_tp_debug_phase_cycles(const e3_tp_plan* plan, unsigned long long out[8]) {
+  if (!plan || !out || !plan->fast.dev.prof) return E3_ERR_UNSUPPORTED;
+  E3_HIP_CHECK(hipDeviceSynchronize());
+  unsigned long long tmp[8];
+  E3_HIP_CHECK(hipMemcpy(tmp, plan->fast.dev.prof, sizeof(tmp), hipMemcpyDeviceToHost));
+  for (int i = 0; i < 8; ++i) out[i] = tmp[i];
+  E3_HIP_CHECK(hipMemset(plan->fast.dev.prof, 0, sizeof(tmp)));
+  return E3_OK;
+}
+
 int e3_tp_fused_supported(const e3_tp_plan* plan, int gate) {
   if (!plan || !plan->fast.usable) return 0;
   if (!gate) return 1;

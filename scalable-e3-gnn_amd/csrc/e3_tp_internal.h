@@ -13,6 +13,10 @@ struct FChunk {  // one piece (<= 32 channels) of an in1 irreps block, natural p
   int col, count, l1;
   int wrow[3][3];  // [l2][l3]: first packed weight row in class l3's matrix, -1 = no coupling
   int wblk[3][3];  // same for the bf16-split layout, in blocks of 16 rows
+  // staging geometry of the bf16-pipe kernels, [0] fp32 storage (4 elements per 16-byte unit), [1] bf16 storage (8):
+  // S = 16-byte units per LDS row (odd), rows_per = rows one 64-lane DMA instruction covers, inv = ceil(2^16 / S)
+  // (lane / S == (lane * inv) >> 16 for lane < 64, checked at plan time)
+  int S[2], rows_per[2], inv[2];
 };
 struct FDev {
   int Dout, Dy, nchunks, nwaves, nbuf, w_in_lds, wtotal, ntab, lsh;
@@ -21,6 +25,7 @@ struct FDev {
   int bf;            // fp32-storage mode: 1 = bf16x3-split kernel, 0 = exact fp32 MFMA kernel
   int bfoff[3];      // element offset (uint16) of class l3 inside Whi (and inside Wlo)
   int bftotal;       // uint16 elements of Whi (== Wlo)
+  unsigned long long* prof;  // per-phase cycle sums (E3_TP_DBG & 8), else nullptr
   int dbg;           // diagnostic build knobs (E3_TP_DBG): 1 = skip output stores, 2 = stage inputs only for the first tile, 4 = skip MFMA runs
 };
 struct FPack { int l3, orig_row, count, wrow, wblk; };

@@ -27,8 +27,8 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void glb_void_t;
 
 constexpr int kFastLds = 160 * 1024;
-constexpr int kChunkFloats = 32 * 161;  // 32 rows x (32 ch x 5 comps | 1)
-constexpr int kChunk16 = 32 * 81;       // bf16 storage: 32 rows x (80 dwords | 1) (>= 16 rows x 161 floats for the out tile)
+constexpr int kChunkFloats = 32 * 41 * 4;  // fp32 storage: 32 rows x 41 16-byte units (40 data units for 32 ch x 5 comps + 1 pad)
+constexpr int kChunk16 = 32 * 21 * 4;      // bf16 storage: 32 rows x 21 units (>= 16 rows x 161 floats for the out tile)
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
@@ -211,10 +211,13 @@ __device__ __forceinline__ void run_steps_bf(const float* __restrict__ xr, const
       ah[t] = whi[(2 * kb) * Mpad + 32 * t];
       al[t] = wlo[(2 * kb) * Mpad + 32 * t];
     }
+    // this lane's 8 channels x D1 components are 2*D1 consecutive 16-byte units of its (16-byte aligned) row
+    const float4* xv = reinterpret_cast<const float4*>(xp + 16 * kb * D1);
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int m = 0; m < D1; ++m) x[i][m] = xp[(16 * kb + i) * D1 + m];
+    for (int u = 0; u < 2 * D1; ++u) {
+      const float4 v = xv[u];
+      (&x[0][0])[4 * u + 0] = v.x; (&x[0][0])[4 * u + 1] = v.y; (&x[0][0])[4 * u + 2] = v.z; (&x[0][0])[4 * u + 3] = v.w;
+    }
   };
   auto compute = [&](int kb, const uint4 (&ah)[NT], const uint4 (&al)[NT], const float (&x)[8][D1]) {
     (void)kb;
@@ -324,8 +327,12 @@ __device__ __forceinline__ void run_steps_io16(const uint32_t* __restrict__ xr32
   auto load = [&](int kb, uint4 (&ah)[NT], uint32_t (&q)[NQ]) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) ah[t] = whi[(2 * kb) * Mpad + 32 * t];
+    const uint4* xv = reinterpret_cast<const uint4*>(xp + 8 * kb * D1);  // D1 consecutive 16-byte units
 #pragma unroll
-    for (int i = 0; i < NQ; ++i) q[i] = xp[8 * kb * D1 + i];
+    for (int u = 0; u < D1; ++u) {
+      const uint4 v = xv[u];
+      q[4 * u + 0] = v.x; q[4 * u + 1] = v.y; q[4 * u + 2] = v.z; q[4 * u + 3] = v.w;
+    }
   };
   auto compute = [&](const uint4 (&ah)[NT], const uint32_t (&q)[NQ]) {
     float x[8][D1];
@@ -384,7 +391,9 @@ struct SegArgs {
   int nseg;
 };
 
-__device__ __forceinline__ float sigmoid_(float v) { return 1.0f / (1.0f + __expf(-v)); }
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float sigmoid_(float v) { return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
 // LSH = SH degree of in2; NT* = number of 32-channel output tiles per degree; L1S... = degrees of the input
 // chunks in order (compile-time so that the chunk walk is straight-line code: no control-flow merges of the
@@ -437,82 +446,152 @@ __global__ __launch_bounds__(256) void tp_fwd_mfma_kernel(SegArgs segs, const fl
 
   const int64_t ntiles = (B + 31) / 32;
   const int64_t tstride = (int64_t)gridDim.x * nwaves;
+  // diagnostic phase timers (E3_TP_DBG & 8): 0 prologue issue, 1 waits for staged data, 2 stage issue, 3 runs, 4 epilogue: gate + transpose into LDS, 5 epilogue: norm + stores
+  unsigned long long* const prof = dp->prof;
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+  auto tick = [&](int phase) {
+    if (prof) {
+      const unsigned long long now = __builtin_amdgcn_s_memtime();
+      tacc[phase] += now - tlast;
+      tlast = now;
+    }
+  };
+  if (prof) tlast = __builtin_amdgcn_s_memtime();
+
+  // row ids of the gathered segments, this lane's row (lane & 31), fetched one tile ahead so that no stage call
+  // waits on an index load
+  // (named scalars, not arrays: an indexed array lands in scratch memory)
+  int mc0 = 0, mc1 = 0, mc2 = 0, mc3 = 0, mn0 = 0, mn1 = 0, mn2 = 0, mn3 = 0;
+  auto fetch_ids = [&](int64_t t) {
+    const int64_t r = t * 32 + j;
+    if (r < B) {
+      if (segs.nseg > 0 && segs.index[0]) mn0 = segs.index[0][r];
+      if (segs.nseg > 1 && segs.index[1]) mn1 = segs.index[1][r];
+      if (segs.nseg > 2 && segs.index[2]) mn2 = segs.index[2][r];
+      if (segs.nseg > 3 && segs.index[3]) mn3 = segs.index[3][r];
+    }
+  };
+  if ((int64_t)blockIdx.x * nwaves + wave < ntiles) fetch_ids((int64_t)blockIdx.x * nwaves + wave);
+  const int inv_dy = (65536 + Dy - 1) / Dy;  // e / Dy == (e * inv_dy) >> 16 for e < 32 * Dy (Dy <= 9)
 
   for (int64_t tile = (int64_t)blockIdx.x * nwaves + wave; tile < ntiles; tile += tstride) {
     const int64_t row0 = tile * 32;
     const int nrows = (int)((B - row0) < 32 ? (B - row0) : 32);
+    mc0 = mn0; mc1 = mn1; mc2 = mn2; mc3 = mn3;
+    if (tile + tstride < ntiles) fetch_ids(tile + tstride);
 
     // stage one chunk of 32 rows (LDS-DMA; per-row gather through the segment's row index).  Row stride (dwords) is
     // odd => the lane=row reads are bank-conflict free.  BF modes zero-pad the chunk to a multiple of 16 channels.
     auto stage = [&](int ci, float* dst) {
       if ((dbg & 2) && tile != (int64_t)blockIdx.x * nwaves + wave) return;
       const FChunk ch = chunks[ci];
-      int s = 0;
-      while (s + 1 < segs.nseg && ch.col >= segs.col0[s + 1]) ++s;
-      const int64_t ld = segs.ld[s];
-      const int32_t* idx = segs.index[s];
-      const int segcol = ch.col - segs.col0[s];
-      const int cw = ch.count * (2 * ch.l1 + 1);                                   // elements per row
-      const int cwp = BF ? ((ch.count + 15) & ~15) * (2 * ch.l1 + 1) : cw;         // padded elements per row
-      const int dw = IO16 ? (cw >> 1) : cw;                                        // whole dwords per row to DMA
-      const int dwp = IO16 ? (cwp >> 1) : cwp;                                     // dwords per padded row
-      const int stride = dwp | 1;
-      int64_t myrow = row0 + j;
-      if (idx && j < nrows) myrow = idx[row0 + j];
-      const int mr = (int)myrow;  // row ids fit int32 (N, E < 2^31)
-      if (cwp > cw) {  // zero the padding (small chunks only, e.g. the distance scalar)
-        for (int r = 0; r < 32; ++r)
-          for (int dc = dw + lane; dc < dwp; dc += 64) dst[r * stride + dc] = 0.f;
-      }
-      if (IO16 && ((cw & 1) || (segcol & 1) || (ld & 1))) {
-        // odd widths / 2-byte aligned sources (e.g. the distance scalar, a single 1o channel): the dword DMA cannot be
-        // used; copy element-wise through registers (tiny chunks only)
-        const uint16_t* b16 = reinterpret_cast<const uint16_t*>(segs.base[s]);
-        uint16_t* d16 = reinterpret_cast<uint16_t*>(dst);
-        for (int r = 0; r < 32; ++r) {
-          const int rr = __builtin_amdgcn_readlane(mr, r < nrows ? r : 0);
-          for (int e = lane; e < cw; e += 64)
-            d16[r * stride * 2 + e] = (r < nrows) ? b16[(int64_t)rr * ld + segcol + e] : (uint16_t)0;
+      // segment of this chunk; constant subscripts only -- a runtime subscript into the by-value argument struct
+      // forces the whole struct into scratch memory and every use becomes a scratch load
+      const int s = (segs.nseg > 1 && ch.col >= segs.col0[1]) + (segs.nseg > 2 && ch.col >= segs.col0[2]) +
+                    (segs.nseg > 3 && ch.col >= segs.col0[3]);
+      auto pick = [&](auto v0, auto v1, auto v2, auto v3) {
+        auto v = v0;
+        v = s == 1 ? v1 : v;
+        v = s == 2 ? v2 : v;
+        v = s == 3 ? v3 : v;
+        return v;
+      };
+      const int64_t ld = pick(segs.ld[0], segs.ld[1], segs.ld[2], segs.ld[3]);
+      const int32_t* idx = pick(segs.index[0], segs.index[1], segs.index[2], segs.index[3]);
+      const void* segbase = pick(segs.base[0], segs.base[1], segs.base[2], segs.base[3]);
+      const int segcol = ch.col - pick(segs.col0[0], segs.col0[1], segs.col0[2], segs.col0[3]);
+      const int cw = ch.count * (2 * ch.l1 + 1);  // elements per row
+      // this lane's row id (lane & 31): prefetched a tile ahead for gathered segments (`mcur`)
+      const int mg = pick(mc0, mc1, mc2, mc3);
+      const int mr = idx ? mg : (int)row0 + j;  // row ids fit int32 (N, E < 2^31)
+      if constexpr (BF) {
+        // Layout: rows of S 16-byte units, S odd (=> the lane=row ds_read_b128 of the operand loads are conflict
+        // free), the chunk zero-padded to a multiple of 16 channels.  Staging: 16-byte LDS-DMA, lane = (row, unit),
+        // several rows per instruction; the per-lane source address does the gather.  (4-byte DMAs run at a quarter
+        // of the 16-byte rate and made staging ~45 % of the kernel.)  The wave is alone on its SIMD, so this code is
+        // priced in issued instructions: S / rows_per / the lane split come precomputed with the chunk.
+        constexpr int ESZ = IO16 ? 2 : 4, EPU = 16 / ESZ, MI = IO16 ? 1 : 0;
+        const int cwp = ((ch.count + 15) & ~15) * (2 * ch.l1 + 1);
+        const int upr = cw / EPU, S = ch.S[MI];
+        const char* base = reinterpret_cast<const char*>(segbase);
+        const bool wide = (cw % EPU == 0) && (segcol % EPU == 0) && (ld % EPU == 0) &&
+                          ((reinterpret_cast<uintptr_t>(base) & 15) == 0);
+        if (wide) {
+          const int rows_per = ch.rows_per[MI];
+          const int rl = (lane * ch.inv[MI]) >> 16, u = lane - rl * S;
+          const bool lane_ok = rl < rows_per && u < upr;
+          const char* lsrc = base + (int64_t)segcol * ESZ + u * 16;
+          const uint32_t ldb = (uint32_t)(ld * ESZ);  // row stride in bytes (< 2^32, checked by the host)
+          for (int r0 = 0; r0 < 32; r0 += 4 * rows_per) {  // 4 DMA instructions per batch: index fetches first
+            int ridx[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ridx[k] = __shfl(mr, (r0 + k * rows_per + rl) & 31);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const int rbase = r0 + k * rows_per;
+              if (rbase < 32 && lane_ok && rbase + rl < nrows)
+                __builtin_amdgcn_global_load_lds((glb_void_t*)(lsrc + (uint64_t)(uint32_t)ridx[k] * ldb),
+                                                 (lds_void_t*)(dst + rbase * S * 4), 16, 0, 0);
+            }
+          }
+          // zero what the copies did not write: padding channels, and every column of rows beyond the batch
+          if (cwp > cw || nrows < 32) {
+            uint16_t* d16 = reinterpret_cast<uint16_t*>(dst);
+            for (int r = 0; r < 32; ++r) {
+              const int e0 = (r < nrows) ? cw : 0;
+              for (int e = e0 + lane; e < cwp; e += 64) {
+                if (IO16) d16[r * S * 8 + e] = 0;
+                else dst[r * S * 4 + e] = 0.f;
+              }
+            }
+          }
+        } else {
+          // narrow or unaligned chunks (the distance scalar, single channels): through registers, lane = (row, parity
+          // of the element index), all rows in flight at once; padding and tail rows are written as zeros
+          const bool rok = j < nrows;
+          if (IO16) {
+            uint16_t* drow = reinterpret_cast<uint16_t*>(dst) + j * S * 8;
+            const uint16_t* srow = reinterpret_cast<const uint16_t*>(base) + (int64_t)mr * ld + segcol;
+            for (int e = half; e < cwp; e += 2) drow[e] = (rok && e < cw) ? srow[e] : (uint16_t)0;
+          } else {
+            float* drow = dst + j * S * 4;
+            const float* srow = reinterpret_cast<const float*>(base) + (int64_t)mr * ld + segcol;
+            for (int e = half; e < cwp; e += 2) drow[e] = (rok && e < cw) ? srow[e] : 0.f;
+          }
         }
         return;
-      }
-      if (!IO16 && cw == 1) {  // one column (the distance scalar): lane r fetches row r
-        const float* base = reinterpret_cast<const float*>(segs.base[s]);
-        if (stride == 1) {
+      } else {
+        const int stride = cw | 1;
+        const float* base = reinterpret_cast<const float*>(segbase);
+        if (cw == 1) {  // one column (the distance scalar): lane r fetches row r
           if (lane < nrows)
             __builtin_amdgcn_global_load_lds((glb_void_t*)(base + (int64_t)mr * ld + segcol), (lds_void_t*)dst, 4, 0, 0);
           else if (lane < 32)
             dst[lane] = 0.f;
-        } else if (lane < 32) {  // padded rows are not contiguous: the DMA cannot scatter, use a register load
-          dst[lane * stride] = (lane < nrows) ? base[(int64_t)mr * ld + segcol] : 0.f;
+          return;
         }
-        return;
-      }
-      const int full = dw & ~63;
-      float* drow = dst;
-      for (int r = 0; r < 32; ++r) {
-        if (r < nrows) {
-          const int rr = __builtin_amdgcn_readlane(mr, r);
-          const float* srow;  // dword view of the source row segment (+ lane)
-          if (IO16)
-            srow = reinterpret_cast<const float*>(reinterpret_cast<const uint16_t*>(segs.base[s]) + (int64_t)rr * ld + segcol) + lane;
-          else
-            srow = reinterpret_cast<const float*>(segs.base[s]) + (int64_t)rr * ld + segcol + lane;
-          for (int dc = 0; dc < full; dc += 64)
-            __builtin_amdgcn_global_load_lds((glb_void_t*)(srow + dc), (lds_void_t*)(drow + dc), 4, 0, 0);
-          if (full + lane < dw)
-            __builtin_amdgcn_global_load_lds((glb_void_t*)(srow + full), (lds_void_t*)(drow + full), 4, 0, 0);
-        } else {
-          for (int dc = lane; dc < dw; dc += 64) drow[dc] = 0.f;
+        const int full = cw & ~63;
+        float* drow = dst;
+        for (int r = 0; r < 32; ++r) {
+          if (r < nrows) {
+            const int rr = __builtin_amdgcn_readlane(mr, r);
+            const float* srow = base + (int64_t)rr * ld + segcol + lane;
+            for (int dc = 0; dc < full; dc += 64)
+              __builtin_amdgcn_global_load_lds((glb_void_t*)(srow + dc), (lds_void_t*)(drow + dc), 4, 0, 0);
+            if (full + lane < cw)
+              __builtin_amdgcn_global_load_lds((glb_void_t*)(srow + full), (lds_void_t*)(drow + full), 4, 0, 0);
+          } else {
+            for (int dc = lane; dc < cw; dc += 64) drow[dc] = 0.f;
+          }
+          drow += stride;
         }
-        drow += stride;
       }
     };
 
     // Y tile [32][Dy] fp32 (lane e of piece h fetches element h*64+e of the flattened tile)
     for (int h = 0; h * 64 < 32 * Dy; ++h) {
       const int e = h * 64 + lane;
-      const int yr = e / Dy, yc = e - yr * Dy;
+      const int yr = (e * inv_dy) >> 16, yc = e - yr * Dy;
       if (e < 32 * Dy) {
         if (yr < nrows)
           __builtin_amdgcn_global_load_lds((glb_void_t*)(in2 + (row0 + yr) * ld2 + yc), (lds_void_t*)(ybuf + h * 64), 4,
@@ -522,6 +601,7 @@ __global__ __launch_bounds__(256) void tp_fwd_mfma_kernel(SegArgs segs, const fl
       }
     }
     stage(0, cbuf);
+    tick(0);
 
     f32x16 a0[NT0 > 0 ? NT0 : 1][1], a1[NT1 > 0 ? NT1 : 1][3], a2[NT2 > 0 ? NT2 : 1][5];
 #pragma unroll
@@ -542,16 +622,18 @@ __global__ __launch_bounds__(256) void tp_fwd_mfma_kernel(SegArgs segs, const fl
       constexpr int L1 = decltype(l1tag)::value;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       wave_sync_lds();
+      tick(1);
       if (ci == 0) {
 #pragma unroll
         for (int q = 0; q < 9; ++q) y[q] = (q < Dy) ? ybuf[j * Dy + q] : 0.f;
       }
       const float* xt = cbuf + cur * CHUNK;
       if (nbuf == 2 && ci + 1 < nchunks) stage(ci + 1, cbuf + (cur ^ 1) * CHUNK);
+      tick(2);
       const FChunk ch = chunks[ci];
+      // row stride: exact mode = odd dword count; bf16-pipe modes = S 16-byte units, S odd (see `stage`)
       const int cwp = (BF ? ((ch.count + 15) & ~15) : ch.count) * (2 * L1 + 1);
-      const int dwp = IO16 ? (cwp >> 1) : cwp;
-      const float* xr = xt + j * (dwp | 1);
+      const float* xr = BF ? xt + j * (((cwp / (IO16 ? 8 : 4)) | 1) * 4) : xt + j * (cwp | 1);
 #define E3_RUN(L2v, L3v, ACC, NTv)                                                                             \
   if constexpr (NTv > 0 && L2v <= LSH && CG<L1, L2v, L3v>::valid && ((L1 + L2v + L3v) % 2 == 0)) {             \
     if (dbg & 4) {                                                                                             \
@@ -571,9 +653,11 @@ __global__ __launch_bounds__(256) void tp_fwd_mfma_kernel(SegArgs segs, const fl
       E3_RUN(0, 1, a1, NT1) E3_RUN(1, 1, a1, NT1) E3_RUN(2, 1, a1, NT1)
       E3_RUN(0, 2, a2, NT2) E3_RUN(1, 2, a2, NT2) E3_RUN(2, 2, a2, NT2)
 #undef E3_RUN
+      tick(3);
       if (nbuf == 1) {
         wave_sync_lds();
         if (ci + 1 < nchunks) stage(ci + 1, cbuf);
+        tick(2);
       } else {
         cur ^= 1;
       }
@@ -581,64 +665,80 @@ __global__ __launch_bounds__(256) void tp_fwd_mfma_kernel(SegArgs segs, const fl
     };
     (process(std::integral_constant<int, L1S>{}), ...);
 
-    // ---- epilogue: norm (+ gate) in registers, transpose through LDS, coalesced stores ----
-    // Every input chunk is consumed, so the chunk buffer becomes the out tile.  fp32 modes: one pass of 32 rows;
-    // bf16 storage: two passes of 16 rows (the buffer is half as large), values rounded to bf16 on the way out.
+    // ---- epilogue: (gate in registers,) transpose through LDS, norm + coalesced 16-byte stores ----
+    // Every input chunk is consumed, so the chunk buffer becomes the out tile.  fp32 modes: one pass over the 32
+    // channels of a tile; bf16 storage (buffer half as large): two passes of 16 channels, rounded to bf16 on the way
+    // out.  The wave is alone on its SIMD, so the epilogue is priced in issued instructions: the norm is applied
+    // after the transpose (one table entry per written column instead of two dependent lookups per accumulator
+    // register) and each lane moves four consecutive columns per instruction.
     wave_sync_lds();
     float* ot = cbuf;
-    constexpr int NPASS = IO16 ? 2 : 1, RP = 32 / NPASS;
+    constexpr int NPASS = IO16 ? 2 : 1, NCH = 32 / NPASS, RPP = 16 / NPASS;
     auto chan_of = [&](int r) { return 8 * (r >> 2) + 4 * half + (r & 3); };
+    const bool out_vec = !(ldo & 3) && ((reinterpret_cast<uintptr_t>(outv) & 15) == 0);
     // emit one job: this lane's values val(r,c) (reg r, component c) of a tile with D components per channel; the
-    // tile-local index lc = D*channel + c maps to global column col(lc); `width` = valid lc count; `affine`: col(lc)
-    // = col(0) + lc (then bf16 pairs are stored as dwords).
-    auto emit = [&](auto dtag, auto val, auto col, const int width, const bool affine) {
+    // tile-local index lc = D*channel + c is written to column col(lc) after multiplication by nrm[ncol(lc)]
+    // (ncol < 0: no norm); `width` = valid lc count; `affine`: col(lc) = col(0) + lc and ncol(lc) = ncol(0) + lc.
+    auto emit = [&](auto dtag, auto val, auto col, auto ncol, const int width, const bool affine) {
       constexpr int D = decltype(dtag)::value;
-      constexpr int TS = (32 * D) | 1;
+      constexpr int TS = NCH * D + 4;    // row stride, dwords: 4 * odd (16-byte aligned rows, spread over the banks)
+      constexpr int UPR = NCH * D / 4;   // 4-column units per row and pass
+      const int colb = col(0), ncolb = ncol(0);
+      const bool vec = affine && out_vec && !(colb & 3) && !(width & 3);
+#pragma unroll
       for (int ps = 0; ps < NPASS; ++ps) {
-        if ((j / RP) == ps) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
+        for (int r = 0; r < RPP; ++r)
 #pragma unroll
-            for (int c = 0; c < D; ++c) ot[(j % RP) * TS + D * chan_of(r) + c] = val(r, c);
-        }
+          for (int c = 0; c < D; ++c) ot[j * TS + D * (chan_of(ps * RPP + r) - ps * NCH) + c] = val(ps * RPP + r, c);
         wave_sync_lds();
-        const int r0 = ps * RP, r1 = (nrows < r0 + RP) ? nrows : r0 + RP;
-        if (!IO16) {
-          float* const obase = reinterpret_cast<float*>(outv) + row0 * ldo;
-          for (int lc = lane; lc < width; lc += 64) {
-            uint32_t off = (uint32_t)col(lc) + (uint32_t)r0 * (uint32_t)ldo;
-            const float* src = ot + lc;
-            for (int r = r0; r < r1; ++r) { if (!(dbg & 1)) obase[off] = *src; off += (uint32_t)ldo; src += TS; }
+        tick(4);
+        if (vec) {
+#pragma unroll 1  // rolled: unrolling lets the scheduler hoist every LDS read and spill the live accumulators
+          for (int it = 0; it < UPR / 2; ++it) {
+            const int u = it * 64 + lane;
+            const int row = u / UPR, un = u - row * UPR;
+            const int lc0 = ps * NCH * D + un * 4;
+            float4 v = *reinterpret_cast<const float4*>(ot + row * TS + un * 4);
+            if (row < nrows && lc0 < width && !(dbg & 1)) {
+              if (ncolb >= 0) {
+                const float* np = nrm + ncolb + lc0;
+                v.x *= np[0]; v.y *= np[1]; v.z *= np[2]; v.w *= np[3];
+              }
+              const int64_t o = (row0 + row) * ldo + colb + lc0;
+              if (IO16) {
+                uint2 pk;
+                pk.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{v.x, v.y}, bf16x2_t));
+                pk.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{v.z, v.w}, bf16x2_t));
+                *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(outv) + o) = pk;
+              } else {
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(outv) + o) = v;
+              }
+            }
           }
         } else {
-          uint16_t* const obase = reinterpret_cast<uint16_t*>(outv) + row0 * ldo;
-          if (affine && !(width & 1) && !(col(0) & 1) && !(ldo & 1)) {
-            uint32_t* const ob32 = reinterpret_cast<uint32_t*>(obase);
-            const uint32_t c0 = (uint32_t)col(0) >> 1, ld32 = (uint32_t)ldo >> 1;
-            for (int q = lane; q < (width >> 1); q += 64) {
-              uint32_t off = c0 + q + (uint32_t)r0 * ld32;
-              const float* src = ot + 2 * q;
-              for (int r = r0; r < r1; ++r) {
-                const uint32_t lo = __builtin_bit_cast(uint16_t, (__bf16)src[0]);
-                const uint32_t hi = __builtin_bit_cast(uint16_t, (__bf16)src[1]);
-                if (!(dbg & 1)) ob32[off] = lo | (hi << 16);
-                off += ld32;
-                src += TS;
-              }
-            }
-          } else {
-            for (int lc = lane; lc < width; lc += 64) {
-              uint32_t off = (uint32_t)col(lc) + (uint32_t)r0 * (uint32_t)ldo;
-              const float* src = ot + lc;
-              for (int r = r0; r < r1; ++r) {
-                if (!(dbg & 1)) obase[off] = __builtin_bit_cast(uint16_t, (__bf16)*src);
-                off += (uint32_t)ldo;
-                src += TS;
-              }
+          for (int lc = lane; lc < NCH * D; lc += 64) {
+            const int glc = ps * NCH * D + lc;
+            if (glc >= width) continue;
+            const int64_t c0 = row0 * ldo + col(glc);
+            const int nc = ncol(glc);
+            const float nv = nc >= 0 ? nrm[nc] : 1.f;
+            const float* src = ot + lc;
+            // cold path (unaligned or scattered columns): rolled on purpose -- unrolled, its 32 row offsets were hoisted
+            // out of the tile loop and spilled
+#pragma unroll 1
+            for (int r = 0; r < nrows; ++r) {
+              const float v = src[r * TS] * nv;
+              if (dbg & 1) continue;
+              if (IO16)
+                reinterpret_cast<uint16_t*>(outv)[c0 + (int64_t)r * ldo] = __builtin_bit_cast(uint16_t, (__bf16)v);
+              else
+                reinterpret_cast<float*>(outv)[c0 + (int64_t)r * ldo] = v;
             }
           }
         }
         wave_sync_lds();
+        tick(5);
       }
     };
     using I1 = std::integral_constant<int, 1>;
@@ -648,14 +748,15 @@ __global__ __launch_bounds__(256) void tp_fwd_mfma_kernel(SegArgs segs, const fl
       // TP out irreps = [32 scalars | 32 gates per gated block | 32x1o | 32x2e]: a0[0] scalars, a0[1..] gates;
       // written layout = [silu(s) (32) | sigmoid(g1) v1 (96) | sigmoid(g2) v2 (160)]
       emit(I1{}, [&](int r, int) { const float s = a0[0][0][r] * nrm[ocl[cOoff[0] + chan_of(r)]]; return s * sigmoid_(s); },
-           [&](int lc) { return lc; }, 32, true);
+           [&](int lc) { return lc; }, [&](int) { return -1; }, 32, true);
       int ocol = 32;
       if (NT1 > 0) {
         float g[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) g[r] = sigmoid_(a0[NT0 > 1 ? 1 : 0][0][r] * nrm[ocl[cOoff[0] + 32 + chan_of(r)]]);
-        emit(I3{}, [&](int r, int c) { return g[r] * a1[0][c][r] * nrm[ocl[cOoff[1] + chan_of(r)] + c]; },
-             [&](int lc) { return ocol + lc; }, 96, true);
+        const int nb = ocl[cOoff[1]];
+        emit(I3{}, [&](int r, int c) { return g[r] * a1[0][c][r]; }, [&](int lc) { return ocol + lc; },
+             [&](int lc) { return nb + lc; }, 96, true);
         ocol += 96;
       }
       if (NT2 > 0) {
@@ -663,32 +764,32 @@ __global__ __launch_bounds__(256) void tp_fwd_mfma_kernel(SegArgs segs, const fl
         float g[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) g[r] = sigmoid_(a0[NT0 > G2 ? G2 : 0][0][r] * nrm[ocl[cOoff[0] + 32 * G2 + chan_of(r)]]);
-        emit(I5{}, [&](int r, int c) { return g[r] * a2[0][c][r] * nrm[ocl[cOoff[2] + chan_of(r)] + c]; },
-             [&](int lc) { return ocol + lc; }, 160, true);
+        const int nb = ocl[cOoff[2]];
+        emit(I5{}, [&](int r, int c) { return g[r] * a2[0][c][r]; }, [&](int lc) { return ocol + lc; },
+             [&](int lc) { return nb + lc; }, 160, true);
       }
     } else {
-      // channels of a tile may belong to several irreps blocks: per-channel column lookup; padded channels
-      // (>= M) map to column 0 of a clamped entry and are never copied (lc >= width)
-      auto nrm_of = [&](int l3, int t, int r, int c) {
-        const int chn = t * 32 + chan_of(r);
-        return chn < cM[l3] ? nrm[ocl[cOoff[l3] + chn] + c] : 0.f;
+      // channels of a tile may belong to several irreps blocks: per-channel column lookup unless the tile's columns
+      // are contiguous (one block); padded channels (>= M) are never copied (lc >= width)
+      auto tile = [&](auto dtag, int l3, int t, auto val) {
+        constexpr int D = decltype(dtag)::value;
+        const int base = cOoff[l3] + t * 32;
+        const int cnt = cM[l3] - t * 32 < 32 ? cM[l3] - t * 32 : 32;
+        const bool affine = ocl[base + cnt - 1] == ocl[base] + (cnt - 1) * D;
+        auto colf = [&](int lc) { return ocl[base + lc / D] + lc % D; };
+        emit(dtag, val, colf, colf, cnt * D, affine);
       };
 #pragma unroll
-      for (int t = 0; t < NT0; ++t)
-        emit(I1{}, [&](int r, int) { return a0[t][0][r] * nrm_of(0, t, r, 0); },
-             [&](int lc) { return ocl[cOoff[0] + t * 32 + lc]; }, (cM[0] - t * 32 < 32 ? cM[0] - t * 32 : 32), false);
+      for (int t = 0; t < NT0; ++t) tile(I1{}, 0, t, [&](int r, int) { return a0[t][0][r]; });
 #pragma unroll
-      for (int t = 0; t < NT1; ++t)
-        emit(I3{}, [&](int r, int c) { return a1[t][c][r] * nrm_of(1, t, r, c); },
-             [&](int lc) { return ocl[cOoff[1] + t * 32 + lc / 3] + lc % 3; },
-             (cM[1] - t * 32 < 32 ? cM[1] - t * 32 : 32) * 3, false);
+      for (int t = 0; t < NT1; ++t) tile(I3{}, 1, t, [&](int r, int c) { return a1[t][c][r]; });
 #pragma unroll
-      for (int t = 0; t < NT2; ++t)
-        emit(I5{}, [&](int r, int c) { return a2[t][c][r] * nrm_of(2, t, r, c); },
-             [&](int lc) { return ocl[cOoff[2] + t * 32 + lc / 5] + lc % 5; },
-             (cM[2] - t * 32 < 32 ? cM[2] - t * 32 : 32) * 5, false);
+      for (int t = 0; t < NT2; ++t) tile(I5{}, 2, t, [&](int r, int c) { return a2[t][c][r]; });
     }
+    tick(4);
   }
+  if (prof && lane == 0)
+    for (int q = 0; q < 8; ++q) atomicAdd(&prof[q], tacc[q]);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -745,10 +846,14 @@ struct FastKernelEntry {
 //            upd2 (0,1 -> hid), readout (0,1 -> 1o);   l_max 2: the same with (0,1,2) blocks.
 static const std::vector<FastKernelEntry>& fast_kernels() {
   static const std::vector<FastKernelEntry> k = {
+#ifdef E3_TP_SUBSET  // compile-time experiments only: the two l_max 2 message kernels
+      E3_FAST(2, 3, 1, 1, 0, 1, 2, 0, 1, 2, 0), E3_FAST(2, 3, 1, 1, 0, 1, 2),
+#else
       E3_FAST(1, 1, 1, 0, 0, 1),          E3_FAST(1, 2, 1, 0, 0, 1, 0, 1, 0), E3_FAST(1, 2, 1, 0, 0, 1),
       E3_FAST(1, 2, 1, 0, 0, 1, 0, 1),    E3_FAST(1, 0, 1, 0, 0, 1),
       E3_FAST(2, 1, 1, 1, 0, 1),          E3_FAST(2, 3, 1, 1, 0, 1, 2, 0, 1, 2, 0), E3_FAST(2, 3, 1, 1, 0, 1, 2),
       E3_FAST(2, 3, 1, 1, 0, 1, 2, 0, 1, 2), E3_FAST(2, 1, 1, 1, 0, 1, 2),  E3_FAST(2, 0, 1, 0, 0, 1, 2),
+#endif
   };
   return k;
 }
@@ -778,7 +883,8 @@ int fast_plan_init(TpFast* F, const int n[6], const int M[6], int lmax_sh, int D
   }
   d.lsh = lmax_sh;
   d.bf = getenv("E3_TP_EXACT") ? 0 : 1;
-  d.dbg = getenv("E3_TP_DBG") ? atoi(getenv("E3_TP_DBG")) : 0;  // timing-only diagnostics, results are wrong when set  // default: bf16-split operands (fp32-grade accuracy)
+  d.dbg = getenv("E3_TP_DBG") ? atoi(getenv("E3_TP_DBG")) : 0;
+  d.prof = nullptr;  // timing-only diagnostics, results are wrong when set  // default: bf16-split operands (fp32-grade accuracy)
   int next_row[3] = {0, 0, 0};
   int next_blk[3] = {0, 0, 0};
   int chan_seen[3] = {0, 0, 0};  // channels of in class l1 seen so far
@@ -806,6 +912,14 @@ int fast_plan_init(TpFast* F, const int n[6], const int M[6], int lmax_sh, int D
           next_blk[l3] += (ch.count + 15) >> 4;
         }
       chan_seen[l1] += ch.count;
+      for (int m = 0; m < 2; ++m) {
+        const int epu = m ? 8 : 4, cwp = ((ch.count + 15) & ~15) * (2 * l1 + 1);
+        ch.S[m] = (cwp / epu) | 1;
+        ch.rows_per[m] = 64 / ch.S[m];
+        ch.inv[m] = (65536 + ch.S[m] - 1) / ch.S[m];
+        for (int ln = 0; ln < 64; ++ln)
+          if (((ln * ch.inv[m]) >> 16) != ln / ch.S[m]) return E3_ERR_UNSUPPORTED;
+      }
       F->h_chunks.push_back(ch);
     }
   }
@@ -833,9 +947,11 @@ int fast_plan_init(TpFast* F, const int n[6], const int M[6], int lmax_sh, int D
     auto fit = [&](size_t fixed, int nbuf) -> int {
       return fixed + per_wave(nbuf) <= (size_t)kFastLds ? (int)std::min<size_t>(((size_t)kFastLds - fixed) / per_wave(nbuf), 4) : 0;
     };
-    const int w2 = fit(tables + wbytes, 2), w1 = fit(tables + wbytes, 1);
-    if (w2 >= 3) { dd.w_in_lds = 1; dd.nbuf = 2; dd.nwaves = w2; }
-    else if (w1 >= 4) { dd.w_in_lds = 1; dd.nbuf = 1; dd.nwaves = 4; }
+    // One chunk buffer per wave and as many waves as fit: measured, a second buffer never paid (the wave that
+    // issues the copies is the one that consumes them; 3 double-buffered waves lost to 4 single-buffered ones on
+    // every kernel of the SEGNN forward).  E3_TP_NBUF=2 keeps the double-buffered variant reachable.
+    const int w1 = fit(tables + wbytes, 1);
+    if (w1 >= 3) { dd.w_in_lds = 1; dd.nbuf = 1; dd.nwaves = w1; }
     else { dd.w_in_lds = 0; dd.nbuf = 1; dd.nwaves = fit(tables, 1); }
     if (const char* e = getenv("E3_TP_NBUF")) { int v = atoi(e); if (v == 1 || (v == 2 && dd.w_in_lds && fit(tables + wbytes, 2) >= 1)) { dd.nbuf = v; dd.nwaves = fit(tables + (dd.w_in_lds ? wbytes : 0), v); } }
     *lds_bytes = tables + (dd.w_in_lds ? wbytes : 0) + (size_t)dd.nwaves * per_wave(dd.nbuf);
@@ -856,6 +972,13 @@ int fast_upload(TpFast* F) {
   E3_HIP_CHECK(hipMalloc((void**)&F->d_pack, std::max<size_t>(F->h_pack.size(), 1) * sizeof(FPack)));
   if (!F->h_pack.empty())
     E3_HIP_CHECK(hipMemcpy(F->d_pack, F->h_pack.data(), F->h_pack.size() * sizeof(FPack), hipMemcpyHostToDevice));
+  if (F->dev.dbg & 8) {
+    unsigned long long* pr = nullptr;
+    E3_HIP_CHECK(hipMalloc((void**)&pr, 8 * sizeof(unsigned long long)));
+    E3_HIP_CHECK(hipMemset(pr, 0, 8 * sizeof(unsigned long long)));
+    F->dev.prof = pr;
+    F->dev16.prof = pr;
+  }
   E3_HIP_CHECK(hipMalloc((void**)&F->d_dev, sizeof(FDev)));
   E3_HIP_CHECK(hipMemcpy(F->d_dev, &F->dev, sizeof(FDev), hipMemcpyHostToDevice));
   E3_HIP_CHECK(hipMalloc((void**)&F->d_dev16, sizeof(FDev)));
@@ -912,6 +1035,7 @@ int fast_forward(const TpFast* F, const e3_tp_segment* segs, int nseg, int D1, c
   for (int i = 0; i < 4; ++i) { sa.base[i] = nullptr; sa.ld[i] = 0; sa.index[i] = nullptr; }
   for (int i = 0; i < nseg; ++i) {
     if (!segs[i].base || segs[i].ncols <= 0 || segs[i].ld < segs[i].ncols) return E3_ERR_INVALID_ARG;
+    if (segs[i].ld >= (int64_t)1 << 29) return E3_ERR_UNSUPPORTED;  // the kernel forms 32-bit row strides in bytes
     sa.base[i] = segs[i].base;
     sa.ld[i] = segs[i].ld;
     sa.index[i] = segs[i].row_index;
