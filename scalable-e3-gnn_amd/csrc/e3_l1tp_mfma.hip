@@ -378,6 +378,7 @@ __global__ __launch_bounds__(512) void l1tp_fwd_mfma_kernel(const float* __restr
     const int64_t row0 = tile * 32;
     const int nrows = (int)((B - row0) < 32 ? (B - row0) : 32);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // the same wait, visible to the backend's wait-count pass (see e3_tp_mfma.hip)
     wave_sync_lds();
     const float* xt = xbuf + cur * in_sz;
     if (nbuf == 2 && tile + tstride < ntiles) stage(tile + tstride, xbuf + (cur ^ 1) * in_sz);

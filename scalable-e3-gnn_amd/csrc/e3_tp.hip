@@ -265,6 +265,17 @@ int e3_tp_plan_create(const int32_t* in1_blocks, int n_in1, int lmax_sh, const i
     for (int c3 = 0; c3 < 6; ++c3)
       for (int i = 0; i < d.npath[c3]; ++i) by_class[c3].push_back(P->h_paths[d.poff[c3] + i]);
     fast_plan_init(&P->fast, d.n, d.M, lmax_sh, d.Dout, d.Dy, blocks, by_class, d.ocol_off);
+    // fused gate epilogue: every natural-parity out class must be one contiguous run of columns, in class order
+    {
+      bool ok = true;
+      int expect = 0;
+      for (int c : {0, 3, 4}) {
+        const int w = 2 * (c >> 1) + 1;
+        for (int i = 0; i < d.M[c]; ++i) ok = ok && P->h_tables[d.D1 + d.ocol_off[c] + i] == expect + i * w;
+        expect += d.M[c] * w;
+      }
+      P->fast.gate_layout = ok;
+    }
   }
   *plan_out = P;
   return E3_OK;
@@ -378,6 +389,7 @@ int e3_tp_debug_phase_cycles(const e3_tp_plan* plan, unsigned long long out[8]) 
 int e3_tp_fused_supported(const e3_tp_plan* plan, int gate) {
   if (!plan || !plan->fast.usable) return 0;
   if (!gate) return 1;
+  if (!plan->fast.gate_layout) return 0;
   const FDev& d = plan->fast.dev;
   const int nb = (d.NT[1] > 0) + (d.NT[2] > 0);
   return (d.NT[0] == 1 + nb && d.M[0] == 32 * (1 + nb) && (!d.NT[1] || d.M[1] == 32) && (!d.NT[2] || d.M[2] == 32) &&

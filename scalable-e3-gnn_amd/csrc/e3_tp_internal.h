@@ -41,6 +41,7 @@ struct TpFast {
   FPack* d_pack = nullptr;
   FDev* d_dev = nullptr;
   bool usable = false;
+  bool gate_layout = false;  // out irreps are [0e scalars+gates | 1o | 2e], each class one contiguous run (fused gate epilogue)
   size_t lds_bytes = 0;
 };
 

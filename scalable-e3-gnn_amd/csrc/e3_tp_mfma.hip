@@ -33,6 +33,14 @@ constexpr int kChunk16 = 32 * 21 * 4;      // bf16 storage: 32 rows x 21 units (
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
+// Wait for every outstanding vector-memory operation (the LDS-DMA copies).  The asm is the compiler barrier; the builtin
+// is the same instruction again in a form the backend's wait-count pass can see -- without it the pass believes the
+// copies are still in flight and guards later LDS accesses with its own vmcnt(0), e.g. in every iteration of the
+// epilogue's store loop (which then waits for the previous iteration's global store: ~650 cycles each).
+__device__ __forceinline__ void wait_vm0() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // gfx9 encoding: vmcnt 0, expcnt 7, lgkmcnt 15 (= no wait on those)
+}
 __device__ __forceinline__ void wave_sync_lds() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -161,6 +169,8 @@ __device__ __forceinline__ void run_steps(const float* __restrict__ xr, const in
 }
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
@@ -244,13 +254,17 @@ __device__ __forceinline__ void run_steps_bf(const float* __restrict__ xr, const
         }
         f[i] = b;  // channels beyond `count` were staged as zeros (and their weight rows are zero)
       }
-      bf16x8 bh, bl;
+      // hi/lo split, pairwise: pack two hi parts with one v_cvt_pk, unpack them with a shift / a mask, pack the two
+      // residuals (3 VALU per value instead of 4 for the value-at-a-time form)
+      uint32_t ph[4], pl[4];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const __bf16 h = (__bf16)f[i];
-        bh[i] = h;
-        bl[i] = (__bf16)(f[i] - (float)h);
+      for (int q = 0; q < 4; ++q) {
+        ph[q] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{f[2 * q], f[2 * q + 1]}, bf16x2_t));
+        const float h0 = __builtin_bit_cast(float, ph[q] << 16), h1 = __builtin_bit_cast(float, ph[q] & 0xffff0000u);
+        pl[q] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{f[2 * q] - h0, f[2 * q + 1] - h1}, bf16x2_t));
       }
+      const bf16x8 bh = __builtin_bit_cast(bf16x8, uint4{ph[0], ph[1], ph[2], ph[3]});
+      const bf16x8 bl = __builtin_bit_cast(bf16x8, uint4{pl[0], pl[1], pl[2], pl[3]});
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const bf16x8 wh = __builtin_bit_cast(bf16x8, ah[t]);
@@ -391,8 +405,6 @@ struct SegArgs {
   int nseg;
 };
 
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float sigmoid_(float v) { return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
 // LSH = SH degree of in2; NT* = number of 32-channel output tiles per degree; L1S... = degrees of the input
@@ -429,7 +441,7 @@ __global__ __launch_bounds__(256) void tp_fwd_mfma_kernel(SegArgs segs, const fl
 
   float* wl = lds;
   float* nrm = lds + (WLDS ? wwords : 0);
-  int* ocl = reinterpret_cast<int*>(nrm + ((Dout + 15) & ~15));
+  int* ocl = reinterpret_cast<int*>(nrm + ((Dout + 4 + 15) & ~15));  // nrm[Dout .. Dout+3] = 1 ("no norm" entry)
   float* wbase_lds = reinterpret_cast<float*>(ocl + ((ntab + 15) & ~15));
   const int per_wave = nbuf * CHUNK + 320;
   float* cbuf = wbase_lds + (size_t)wave * per_wave;
@@ -438,6 +450,7 @@ __global__ __launch_bounds__(256) void tp_fwd_mfma_kernel(SegArgs segs, const fl
   if (WLDS)
     for (int i = tid; i < wwords; i += blockDim.x) wl[i] = wglob[i];
   for (int i = tid; i < Dout; i += blockDim.x) nrm[i] = packed[wtotal + i];
+  if (tid < 4) nrm[Dout + tid] = 1.f;
   for (int i = tid; i < ntab; i += blockDim.x) ocl[i] = ocol_tab[i];
   __syncthreads();
   const float* wsrc = WLDS ? wl : wglob;
@@ -620,7 +633,7 @@ __global__ __launch_bounds__(256) void tp_fwd_mfma_kernel(SegArgs segs, const fl
     int ci = 0;
     auto process = [&](auto l1tag) {
       constexpr int L1 = decltype(l1tag)::value;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      wait_vm0();
       wave_sync_lds();
       tick(1);
       if (ci == 0) {
@@ -671,6 +684,7 @@ __global__ __launch_bounds__(256) void tp_fwd_mfma_kernel(SegArgs segs, const fl
     // out.  The wave is alone on its SIMD, so the epilogue is priced in issued instructions: the norm is applied
     // after the transpose (one table entry per written column instead of two dependent lookups per accumulator
     // register) and each lane moves four consecutive columns per instruction.
+    wait_vm0();  // nothing is in flight here; this tells the wait-count pass so (see wait_vm0)
     wave_sync_lds();
     float* ot = cbuf;
     constexpr int NPASS = IO16 ? 2 : 1, NCH = 32 / NPASS, RPP = 16 / NPASS;
@@ -694,25 +708,32 @@ __global__ __launch_bounds__(256) void tp_fwd_mfma_kernel(SegArgs segs, const fl
         wave_sync_lds();
         tick(4);
         if (vec) {
-#pragma unroll 1  // rolled: unrolling lets the scheduler hoist every LDS read and spill the live accumulators
+          // index math in 24-bit multiplies (full rate; 32-bit integer multiplies run at a quarter of it) and a
+          // uniform 64-bit tile base + 32-bit lane offset for the stores
+          constexpr uint32_t INV = (65536 + UPR - 1) / UPR;  // u / UPR == (u * INV) >> 16 for u < 32 * UPR
+          static_assert(((32u * UPR - 1) * INV >> 16) == 31 && ((31u * UPR + UPR - 1) * INV >> 16) == 31 &&
+                        ((31u * UPR) * INV >> 16) == 31 && ((30u * UPR + UPR - 1) * INV >> 16) == 30, "reciprocal");
+          const uint32_t ldo32 = (uint32_t)ldo;
+          const float* nbase = ncolb >= 0 ? nrm + ncolb + ps * NCH * D : nrm + Dout;
+          const uint32_t nstep = ncolb >= 0 ? 4u : 0u;
+#pragma unroll 2  // two in flight; full unrolling lets the scheduler hoist every LDS read and spill the accumulators
           for (int it = 0; it < UPR / 2; ++it) {
-            const int u = it * 64 + lane;
-            const int row = u / UPR, un = u - row * UPR;
-            const int lc0 = ps * NCH * D + un * 4;
-            float4 v = *reinterpret_cast<const float4*>(ot + row * TS + un * 4);
-            if (row < nrows && lc0 < width && !(dbg & 1)) {
-              if (ncolb >= 0) {
-                const float* np = nrm + ncolb + lc0;
-                v.x *= np[0]; v.y *= np[1]; v.z *= np[2]; v.w *= np[3];
-              }
-              const int64_t o = (row0 + row) * ldo + colb + lc0;
+            const uint32_t u = it * 64 + lane;
+            const uint32_t row = __umul24(u, INV) >> 16, un = u - __umul24(row, UPR);
+            const uint32_t lc0 = ps * NCH * D + un * 4;
+            float4 v = *reinterpret_cast<const float4*>(ot + __umul24(row, TS) + un * 4);
+            const float* np = nbase + un * nstep;
+            const float n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+            if ((int)row < nrows && (int)lc0 < width && !(dbg & 1)) {
+              v.x *= n0; v.y *= n1; v.z *= n2; v.w *= n3;
+              const uint32_t o = __umul24(row, ldo32) + (uint32_t)colb + lc0;
               if (IO16) {
                 uint2 pk;
                 pk.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{v.x, v.y}, bf16x2_t));
                 pk.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{v.z, v.w}, bf16x2_t));
-                *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(outv) + o) = pk;
+                *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(outv) + row0 * ldo + o) = pk;
               } else {
-                *reinterpret_cast<float4*>(reinterpret_cast<float*>(outv) + o) = v;
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(outv) + row0 * ldo + o) = v;
               }
             }
           }
@@ -747,13 +768,14 @@ __global__ __launch_bounds__(256) void tp_fwd_mfma_kernel(SegArgs segs, const fl
     if (GATE) {
       // TP out irreps = [32 scalars | 32 gates per gated block | 32x1o | 32x2e]: a0[0] scalars, a0[1..] gates;
       // written layout = [silu(s) (32) | sigmoid(g1) v1 (96) | sigmoid(g2) v2 (160)]
-      emit(I1{}, [&](int r, int) { const float s = a0[0][0][r] * nrm[ocl[cOoff[0] + chan_of(r)]]; return s * sigmoid_(s); },
+      const float* nrm0 = nrm + ocl[cOoff[0]];  // the scalar block is one irreps-contiguous run of 32 * NT0 columns
+      emit(I1{}, [&](int r, int) { const float s = a0[0][0][r] * nrm0[chan_of(r)]; return s * sigmoid_(s); },
            [&](int lc) { return lc; }, [&](int) { return -1; }, 32, true);
       int ocol = 32;
       if (NT1 > 0) {
         float g[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) g[r] = sigmoid_(a0[NT0 > 1 ? 1 : 0][0][r] * nrm[ocl[cOoff[0] + 32 + chan_of(r)]]);
+        for (int r = 0; r < 16; ++r) g[r] = sigmoid_(a0[NT0 > 1 ? 1 : 0][0][r] * nrm0[32 + chan_of(r)]);
         const int nb = ocl[cOoff[1]];
         emit(I3{}, [&](int r, int c) { return g[r] * a1[0][c][r]; }, [&](int lc) { return ocol + lc; },
              [&](int lc) { return nb + lc; }, 96, true);
@@ -763,7 +785,7 @@ __global__ __launch_bounds__(256) void tp_fwd_mfma_kernel(SegArgs segs, const fl
         constexpr int G2 = (NT1 > 0) ? 2 : 1;  // which scalar tile holds the gates of the 2e block
         float g[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) g[r] = sigmoid_(a0[NT0 > G2 ? G2 : 0][0][r] * nrm[ocl[cOoff[0] + 32 * G2 + chan_of(r)]]);
+        for (int r = 0; r < 16; ++r) g[r] = sigmoid_(a0[NT0 > G2 ? G2 : 0][0][r] * nrm0[32 * G2 + chan_of(r)]);
         const int nb = ocl[cOoff[2]];
         emit(I5{}, [&](int r, int c) { return g[r] * a2[0][c][r]; }, [&](int lc) { return ocol + lc; },
              [&](int lc) { return nb + lc; }, 160, true);
@@ -941,7 +963,7 @@ int fast_plan_init(TpFast* F, const int n[6], const int M[6], int lmax_sh, int D
   for (auto& c : F->h_chunks) l1s.push_back(c.l1);
   if (!find_fast(lmax_sh, d.NT[0], d.NT[1], d.NT[2], l1s)) return E3_OK;
   // LDS plan: [weights?][normcol][ocol][nwaves x (nbuf chunk buffers + Y tile)], once per storage class
-  size_t tables = (size_t)((Dout + 15) & ~15) * 4 + (size_t)((ntab + 15) & ~15) * 4;
+  size_t tables = (size_t)((Dout + 4 + 15) & ~15) * 4 + (size_t)((ntab + 15) & ~15) * 4;
   auto lds_plan = [&](FDev& dd, size_t wbytes, int chunk_dwords, size_t* lds_bytes) -> bool {
     auto per_wave = [&](int nbuf) { return (size_t)(nbuf * chunk_dwords + 320) * 4; };
     auto fit = [&](size_t fixed, int nbuf) -> int {
@@ -1032,6 +1054,7 @@ int fast_forward(const TpFast* F, const e3_tp_segment* segs, int nseg, int D1, c
   if (nseg < 1 || nseg > 4) return E3_ERR_INVALID_ARG;
   SegArgs sa;
   int col = 0;
+  if (ldo >= ((int64_t)1 << 24)) return E3_ERR_UNSUPPORTED;  // the store loop uses 24-bit multiplies for row * ldo
   for (int i = 0; i < 4; ++i) { sa.base[i] = nullptr; sa.ld[i] = 0; sa.index[i] = nullptr; }
   for (int i = 0; i < nseg; ++i) {
     if (!segs[i].base || segs[i].ncols <= 0 || segs[i].ld < segs[i].ncols) return E3_ERR_INVALID_ARG;
@@ -1052,7 +1075,7 @@ int fast_forward(const TpFast* F, const e3_tp_segment* segs, int nseg, int D1, c
   }
   if (gate) {
     const int nb = (d.NT[1] > 0) + (d.NT[2] > 0);
-    if (d.NT[0] != 1 + nb || d.M[0] != 32 * (1 + nb) || (d.NT[1] && d.M[1] != 32) || (d.NT[2] && d.M[2] != 32) ||
+    if (!F->gate_layout || d.NT[0] != 1 + nb || d.M[0] != 32 * (1 + nb) || (d.NT[1] && d.M[1] != 32) || (d.NT[2] && d.M[2] != 32) ||
         d.NT[1] > 1 || d.NT[2] > 1)
       return E3_ERR_UNSUPPORTED;
   }
