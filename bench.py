@@ -82,6 +82,8 @@ def main():
                     help="storage type of features / weights (bf16 = BASELINE config 3; l_max=2 only)")
     ap.add_argument("--timing-json", type=str, default=None, help="also dump per-TP timings here")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-bf16-leg", action="store_true",
+                    help="skip the extra timed leg in bf16 storage (BASELINE.json configs[2]) reported as `bf16_storage`")
     args = ap.parse_args()
 
     import models  # noqa: F401
@@ -137,18 +139,20 @@ def main():
     lo = [float(rank) - (2 * r if world > 1 else 0.0), 0.0, 0.0]
     hi = [float(rank) + 1.0 + (2 * r if world > 1 else 0.0), 1.0, 1.0]
 
-    def step():
-        if halo is None:
-            g = radius_graph(pos, r, lo, hi)
-            xs = x[g.perm.long()]
-        else:
-            lpos, lx = halo.setup(pos, x, float(rank), float(rank + 1), r)   # ghost positions + features
-            g = radius_graph(lpos, r, lo, hi)
-            halo.renumber(g.perm)
-            xs = lx[g.perm.long()]
-        with torch.no_grad():
-            out = model(xs, g, halo=halo)
-        return g, out
+    def make_step(model, x):
+        def step():
+            if halo is None:
+                g = radius_graph(pos, r, lo, hi)
+                xs = x[g.perm.long()]
+            else:
+                lpos, lx = halo.setup(pos, x, float(rank), float(rank + 1), r)   # ghost positions + features
+                g = radius_graph(lpos, r, lo, hi)
+                halo.renumber(g.perm)
+                xs = lx[g.perm.long()]
+            with torch.no_grad():
+                out = model(xs, g, halo=halo)
+            return g, out
+        return step
 
     def fence():
         torch.cuda.synchronize()
@@ -156,23 +160,40 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    profiling.enable()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        g, out = step()
-    fence()
-    dt = time.perf_counter() - t0
-    prof = profiling.summary()
-    profiling.disable()
-    if dist is not None:
-        t = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    assert torch.isfinite(out).all()
+    def timed(step, warmup, steps, profile):
+        for _ in range(warmup):
+            step()
+        fence()
+        if profile:
+            profiling.enable()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            g, out = step()
+        fence()
+        dt = time.perf_counter() - t0
+        prof = profiling.summary() if profile else None
+        if profile:
+            profiling.disable()
+        if dist is not None:
+            t = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        assert torch.isfinite(out.float()).all()
+        return dt, g, out, prof
 
+    dt, g, out, prof = timed(make_step(model, x), args.warmup, args.steps, True)
+    # second leg, same workload in bf16 storage (BASELINE.json configs[2]); reported beside the fp32 value, never as it
+    bf16_leg = None
+    if args.dtype == "f32" and args.lmax == 2 and not args.no_bf16_leg:
+        m16 = SEGNN("1x0e+1x1o", args.hidden, "1x1o", args.layers, lmax=args.lmax).to(dev)
+        m16.load_state_dict(model.state_dict())
+        m16 = m16.bfloat16()
+        dt16, _, _, _ = timed(make_step(m16, x.bfloat16()), max(1, args.warmup), args.steps, False)
+        bf16_leg = {"value": n * world / (dt16 / args.steps), "unit": "particles/s", "ms_per_step": dt16 / args.steps * 1e3,
+                    "dtype": "bf16", "steps": args.steps,
+                    "numerics": "bf16 storage of features/weights/messages, fp32 spherical harmonics, bf16 MFMA with "
+                                "fp32 accumulation (tests/test_bf16_gpu.py: within 1e-2 of the fp64 oracle)"}
+        del m16
     if rank == 0:
         ms = dt / args.steps * 1e3
         total_particles = n * world
@@ -223,6 +244,8 @@ def main():
                                        f"p2p exchanges/step over RCCL") if world > 1 else "single GPU"},
             "roofline": roof,
         }
+        if bf16_leg is not None:
+            line["bf16_storage"] = bf16_leg
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, model.state_dict())
         print(json.dumps(line), flush=True)
