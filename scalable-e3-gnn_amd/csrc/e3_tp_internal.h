@@ -26,7 +26,7 @@ struct FDev {
   int bfoff[3];      // element offset (uint16) of class l3 inside Whi (and inside Wlo)
   int bftotal;       // uint16 elements of Whi (== Wlo)
   unsigned long long* prof;  // per-phase cycle sums (E3_TP_DBG & 8), else nullptr
-  int dbg;           // diagnostic build knobs (E3_TP_DBG): 1 = skip output stores, 2 = stage inputs only for the first tile, 4 = skip MFMA runs
+  int dbg;           // diagnostic build knobs (E3_TP_DBG): 1 = skip output stores, 2 = stage inputs only for the first tile, 4 = skip MFMA runs, 8 = phase timers, 16 = skip the LDS-DMA instructions, 32 = skip the weight preload
 };
 struct FPack { int l3, orig_row, count, wrow, wblk; };
 

@@ -184,6 +184,7 @@ __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
 template <int L1, int L2, int L3, int NT>
 __device__ __forceinline__ void run_steps_bf(const float* __restrict__ xr, const int count,
                                              const uint4* __restrict__ whi, const uint4* __restrict__ wlo,
+                                             const uint4* pre_h, const uint4* pre_l,  // A operands of k block 0 (preloaded)
                                              const int Mpad, const int half, const float (&y)[9],
                                              f32x16 (&acc)[NT][2 * L3 + 1]) {
   constexpr int D1 = 2 * L1 + 1, D2 = 2 * L2 + 1, D3 = 2 * L3 + 1;
@@ -215,11 +216,11 @@ __device__ __forceinline__ void run_steps_bf(const float* __restrict__ xr, const
   }
   const float* xp = xr + 8 * half * D1;
   const int nkb = (count + 15) >> 4;
-  auto load = [&](int kb, uint4 (&ah)[NT], uint4 (&al)[NT], float (&x)[8][D1]) {
+  auto load = [&](int kb, uint4 (&ah)[NT], uint4 (&al)[NT], float (&x)[8][D1], bool first = false) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      ah[t] = whi[(2 * kb) * Mpad + 32 * t];
-      al[t] = wlo[(2 * kb) * Mpad + 32 * t];
+      ah[t] = first ? pre_h[t] : whi[(2 * kb) * Mpad + 32 * t];
+      al[t] = first ? pre_l[t] : wlo[(2 * kb) * Mpad + 32 * t];
     }
     // this lane's 8 channels x D1 components are 2*D1 consecutive 16-byte units of its (16-byte aligned) row
     const float4* xv = reinterpret_cast<const float4*>(xp + 16 * kb * D1);
@@ -229,57 +230,87 @@ __device__ __forceinline__ void run_steps_bf(const float* __restrict__ xr, const
       (&x[0][0])[4 * u + 0] = v.x; (&x[0][0])[4 * u + 1] = v.y; (&x[0][0])[4 * u + 2] = v.z; (&x[0][0])[4 * u + 3] = v.w;
     }
   };
+  // Features are built for two output components at a time on the packed-fp32 pipe (v_pk_fma_f32: z pair x broadcast
+  // x), which halves the VALU count of the contraction with z; the hi/lo split works on the same pairs.
   auto compute = [&](int kb, const uint4 (&ah)[NT], const uint4 (&al)[NT], const float (&x)[8][D1]) {
     (void)kb;
 #pragma unroll
-    for (int c = 0; c < NB; ++c) {
-      float f[8];
+    for (int c = 0; c < NB; c += 2) {
+      const bool pr = c + 1 < NB;
+      f32x2_t b2[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        float b = 0.f;
+        f32x2_t b = {0.f, 0.f};
         if (MIX) {
-          b = x[i][c];
+          b.x = x[i][c];
+          if (pr) b.y = x[i][c + 1];
         } else {
-          bool have = false;
+          bool hx = false, hy = false;
 #pragma unroll
           for (int m = 0; m < D1; ++m) {
-            bool nz = false;
+            bool nza = false, nzb = false;
 #pragma unroll
-            for (int q = 0; q < D2; ++q) nz |= (C::v[m][q][c] != 0.0);
-            if (nz) {
-              b = have ? __builtin_fmaf(z[m][c], x[i][m], b) : z[m][c] * x[i][m];
-              have = true;
+            for (int q = 0; q < D2; ++q) {
+              nza |= (C::v[m][q][c] != 0.0);
+              if (pr) nzb |= (C::v[m][q][c + 1 < D3 ? c + 1 : c] != 0.0);
+            }
+            if (nza && nzb) {
+              const f32x2_t z2 = {z[m][c], z[m][c + 1 < D3 ? c + 1 : c]}, xx = {x[i][m], x[i][m]};
+              b = (hx || hy) ? __builtin_elementwise_fma(z2, xx, b) : z2 * xx;
+              hx = hy = true;
+            } else if (nza) {
+              b.x = hx ? __builtin_fmaf(z[m][c], x[i][m], b.x) : z[m][c] * x[i][m];
+              hx = true;
+            } else if (nzb) {
+              b.y = hy ? __builtin_fmaf(z[m][c + 1 < D3 ? c + 1 : c], x[i][m], b.y) : z[m][c + 1 < D3 ? c + 1 : c] * x[i][m];
+              hy = true;
             }
           }
         }
-        f[i] = b;  // channels beyond `count` were staged as zeros (and their weight rows are zero)
+        b2[i] = b;  // channels beyond `count` were staged as zeros (and their weight rows are zero)
       }
-      // hi/lo split, pairwise: pack two hi parts with one v_cvt_pk, unpack them with a shift / a mask, pack the two
-      // residuals (3 VALU per value instead of 4 for the value-at-a-time form)
-      uint32_t ph[4], pl[4];
+      // hi/lo split: hi parts packed two channels at a time (v_cvt_pk), unpacked by shift / mask, residuals on
+      // the packed pipe (one v_pk_add per channel for both components), then packed again
+      uint32_t ph[2][4], pl[2][4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        ph[q] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{f[2 * q], f[2 * q + 1]}, bf16x2_t));
-        const float h0 = __builtin_bit_cast(float, ph[q] << 16), h1 = __builtin_bit_cast(float, ph[q] & 0xffff0000u);
-        pl[q] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{f[2 * q] - h0, f[2 * q + 1] - h1}, bf16x2_t));
+        ph[0][q] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{b2[2 * q].x, b2[2 * q + 1].x}, bf16x2_t));
+        ph[1][q] = pr ? __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{b2[2 * q].y, b2[2 * q + 1].y}, bf16x2_t)) : 0u;
       }
-      const bf16x8 bh = __builtin_bit_cast(bf16x8, uint4{ph[0], ph[1], ph[2], ph[3]});
-      const bf16x8 bl = __builtin_bit_cast(bf16x8, uint4{pl[0], pl[1], pl[2], pl[3]});
+      f32x2_t l2[8];
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const bf16x8 wh = __builtin_bit_cast(bf16x8, ah[t]);
-        const bf16x8 wl = __builtin_bit_cast(bf16x8, al[t]);
-        f32x16& dst = MIX ? T[t][c] : acc[t][c];
-        dst = mfma_bf16(wh, bh, dst);
-        dst = mfma_bf16(wh, bl, dst);
-        dst = mfma_bf16(wl, bh, dst);
+      for (int i = 0; i < 8; ++i) {
+        const uint32_t wa = ph[0][i >> 1], wb = ph[1][i >> 1];
+        const f32x2_t h2 = {__builtin_bit_cast(float, (i & 1) ? (wa & 0xffff0000u) : (wa << 16)),
+                            __builtin_bit_cast(float, (i & 1) ? (wb & 0xffff0000u) : (wb << 16))};
+        l2[i] = b2[i] - h2;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        pl[0][q] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{l2[2 * q].x, l2[2 * q + 1].x}, bf16x2_t));
+        pl[1][q] = pr ? __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{l2[2 * q].y, l2[2 * q + 1].y}, bf16x2_t)) : 0u;
+      }
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc) {
+        if (cc == 1 && !pr) break;
+        const bf16x8 bh = __builtin_bit_cast(bf16x8, uint4{ph[cc][0], ph[cc][1], ph[cc][2], ph[cc][3]});
+        const bf16x8 bl = __builtin_bit_cast(bf16x8, uint4{pl[cc][0], pl[cc][1], pl[cc][2], pl[cc][3]});
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const bf16x8 wh = __builtin_bit_cast(bf16x8, ah[t]);
+          const bf16x8 wl = __builtin_bit_cast(bf16x8, al[t]);
+          f32x16& dst = MIX ? T[t][c + cc] : acc[t][c + cc < D3 ? c + cc : c];
+          dst = mfma_bf16(wh, bh, dst);
+          dst = mfma_bf16(wh, bl, dst);
+          dst = mfma_bf16(wl, bh, dst);
+        }
       }
     }
   };
   {
     uint4 ah[NT], al[NT];
     float x[8][D1];
-    load(0, ah, al, x);
+    load(0, ah, al, x, true);
     for (int kb = 0; kb + 1 < nkb; ++kb) {
       uint4 ahn[NT], aln[NT];
       float xn[8][D1];
@@ -315,7 +346,7 @@ __device__ __forceinline__ void run_steps_bf(const float* __restrict__ xr, const
 // lane's row (dwords); channels beyond `count` were staged as zeros.
 template <int L1, int L2, int L3, int NT>
 __device__ __forceinline__ void run_steps_io16(const uint32_t* __restrict__ xr32, const int count,
-                                               const uint4* __restrict__ whi, const int Mpad, const int half,
+                                               const uint4* __restrict__ whi, const uint4* pre_h, const int Mpad, const int half,
                                                const float (&y)[9], f32x16 (&acc)[NT][2 * L3 + 1]) {
   constexpr int D1 = 2 * L1 + 1, D2 = 2 * L2 + 1, D3 = 2 * L3 + 1;
   constexpr int NQ = 4 * D1;  // dwords holding this lane's 8 channels x D1 components
@@ -338,9 +369,9 @@ __device__ __forceinline__ void run_steps_io16(const uint32_t* __restrict__ xr32
     }
   const uint32_t* xp = xr32 + 4 * half * D1;
   const int nkb = (count + 15) >> 4;
-  auto load = [&](int kb, uint4 (&ah)[NT], uint32_t (&q)[NQ]) {
+  auto load = [&](int kb, uint4 (&ah)[NT], uint32_t (&q)[NQ], bool first = false) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) ah[t] = whi[(2 * kb) * Mpad + 32 * t];
+    for (int t = 0; t < NT; ++t) ah[t] = first ? pre_h[t] : whi[(2 * kb) * Mpad + 32 * t];
     const uint4* xv = reinterpret_cast<const uint4*>(xp + 8 * kb * D1);  // D1 consecutive 16-byte units
 #pragma unroll
     for (int u = 0; u < D1; ++u) {
@@ -356,32 +387,56 @@ __device__ __forceinline__ void run_steps_io16(const uint32_t* __restrict__ xr32
       x[e / D1][e % D1] = __builtin_bit_cast(float, (e & 1) ? (w & 0xffff0000u) : (w << 16));
     }
 #pragma unroll
-    for (int c = 0; c < D3; ++c) {
-      bf16x8 bh;
+    for (int c = 0; c < D3; c += 2) {  // two output components at a time on the packed-fp32 pipe (see run_steps_bf)
+      const bool pr = c + 1 < D3;
+      f32x2_t b2[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        float b = 0.f;
-        bool have = false;
+        f32x2_t b = {0.f, 0.f};
+        bool hx = false, hy = false;
 #pragma unroll
         for (int m = 0; m < D1; ++m) {
-          bool nz = false;
+          bool nza = false, nzb = false;
 #pragma unroll
-          for (int qq = 0; qq < D2; ++qq) nz |= (C::v[m][qq][c] != 0.0);
-          if (nz) {
-            b = have ? __builtin_fmaf(z[m][c], x[i][m], b) : z[m][c] * x[i][m];
-            have = true;
+          for (int qq = 0; qq < D2; ++qq) {
+            nza |= (C::v[m][qq][c] != 0.0);
+            if (pr) nzb |= (C::v[m][qq][c + 1 < D3 ? c + 1 : c] != 0.0);
+          }
+          if (nza && nzb) {
+            const f32x2_t z2 = {z[m][c], z[m][c + 1 < D3 ? c + 1 : c]}, xx = {x[i][m], x[i][m]};
+            b = (hx || hy) ? __builtin_elementwise_fma(z2, xx, b) : z2 * xx;
+            hx = hy = true;
+          } else if (nza) {
+            b.x = hx ? __builtin_fmaf(z[m][c], x[i][m], b.x) : z[m][c] * x[i][m];
+            hx = true;
+          } else if (nzb) {
+            b.y = hy ? __builtin_fmaf(z[m][c + 1 < D3 ? c + 1 : c], x[i][m], b.y) : z[m][c + 1 < D3 ? c + 1 : c] * x[i][m];
+            hy = true;
           }
         }
-        bh[i] = (__bf16)b;
+        b2[i] = b;
       }
 #pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t][c] = mfma_bf16(__builtin_bit_cast(bf16x8, ah[t]), bh, acc[t][c]);
+      for (int cc = 0; cc < 2; ++cc) {
+        if (cc == 1 && !pr) break;
+        uint32_t pk[4];
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq)
+          pk[qq] = __builtin_bit_cast(uint32_t, __builtin_convertvector(
+                       cc ? f32x2_t{b2[2 * qq].y, b2[2 * qq + 1].y} : f32x2_t{b2[2 * qq].x, b2[2 * qq + 1].x}, bf16x2_t));
+        const bf16x8 bh = __builtin_bit_cast(bf16x8, uint4{pk[0], pk[1], pk[2], pk[3]});
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          f32x16& dst = acc[t][c + cc < D3 ? c + cc : c];
+          dst = mfma_bf16(__builtin_bit_cast(bf16x8, ah[t]), bh, dst);
+        }
+      }
     }
   };
   {
     uint4 ah[NT];
     uint32_t q[NQ];
-    load(0, ah, q);
+    load(0, ah, q, true);
     for (int kb = 0; kb + 1 < nkb; ++kb) {
       uint4 ahn[NT];
       uint32_t qn[NQ];
@@ -395,6 +450,44 @@ __device__ __forceinline__ void run_steps_io16(const uint32_t* __restrict__ xr32
     compute(ah, q);
   }
   __builtin_amdgcn_sched_barrier(0);
+}
+
+// Compile-time bookkeeping for the weight preload: the (l2, l3) paths of an input chunk of degree l1 in the order the
+// kernel runs them (l3 outer, l2 inner), each owning nt(l3) consecutive slots of the preload registers.
+template <int LSH, int NT0, int NT1, int NT2>
+struct PathSlots {
+  static constexpr int nt(int l3) { return l3 == 0 ? NT0 : l3 == 1 ? NT1 : NT2; }
+  static constexpr bool valid(int l1, int l2, int l3) {
+    return l1 >= 0 && nt(l3) > 0 && l2 <= LSH && ((l1 + l2 + l3) % 2 == 0) && l3 >= (l1 > l2 ? l1 - l2 : l2 - l1) &&
+           l3 <= l1 + l2;
+  }
+  static constexpr int slot(int l1, int l2, int l3) {
+    int o = 0;
+    for (int c = 0; c < 3; ++c)
+      for (int b = 0; b < 3; ++b) {
+        if (c == l3 && b == l2) return o;
+        if (valid(l1, b, c)) o += nt(c);
+      }
+    return o;
+  }
+  static constexpr int total(int l1) { return slot(l1, 3, 3); }
+  static constexpr int max_total() {
+    int m = 1;
+    for (int l1 = 0; l1 < 3; ++l1) m = total(l1) > m ? total(l1) : m;
+    return m;
+  }
+};
+template <int... V>
+struct IntSeq {
+  static constexpr int n = sizeof...(V);
+  static constexpr int at(int i) {
+    constexpr int a[] = {V...};
+    return (i >= 0 && i < n) ? a[i] : -1;
+  }
+};
+template <class F, size_t... I>
+__device__ __forceinline__ void for_each_index(F&& f, std::index_sequence<I...>) {
+  (f(std::integral_constant<int, (int)I>{}), ...);
 }
 
 struct SegArgs {
@@ -529,7 +622,9 @@ __global__ __launch_bounds__(256) void tp_fwd_mfma_kernel(SegArgs segs, const fl
         const char* base = reinterpret_cast<const char*>(segbase);
         const bool wide = (cw % EPU == 0) && (segcol % EPU == 0) && (ld % EPU == 0) &&
                           ((reinterpret_cast<uintptr_t>(base) & 15) == 0);
-        if (wide) {
+        tick(6);
+        if (dbg & 64) {  // diagnostic: no copies at all
+        } else if (wide) {
           const int rows_per = ch.rows_per[MI];
           const int rl = (lane * ch.inv[MI]) >> 16, u = lane - rl * S;
           const bool lane_ok = rl < rows_per && u < upr;
@@ -542,7 +637,7 @@ __global__ __launch_bounds__(256) void tp_fwd_mfma_kernel(SegArgs segs, const fl
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
               const int rbase = r0 + k * rows_per;
-              if (rbase < 32 && lane_ok && rbase + rl < nrows)
+              if (rbase < 32 && lane_ok && rbase + rl < nrows && !(dbg & 16))
                 __builtin_amdgcn_global_load_lds((glb_void_t*)(lsrc + (uint64_t)(uint32_t)ridx[k] * ldb),
                                                  (lds_void_t*)(dst + rbase * S * 4), 16, 0, 0);
             }
@@ -631,8 +726,36 @@ __global__ __launch_bounds__(256) void tp_fwd_mfma_kernel(SegArgs segs, const fl
     float y[9];
     int cur = 0;
     int ci = 0;
-    auto process = [&](auto l1tag) {
-      constexpr int L1 = decltype(l1tag)::value;
+    // A operands (weights) of the first k block of every path of the NEXT chunk are fetched while the current chunk's
+    // copies are being issued: each path otherwise starts with an exposed L2 (or LDS) round trip -- ~40 paths per
+    // tile, 40 % of the kernel's cycles were s_waitcnt stalls (SQ_WAIT_ANY) before this
+    using Slots = PathSlots<LSH, NT0, NT1, NT2>;
+    using Seq = IntSeq<L1S...>;
+    constexpr int PWN = BF ? Slots::max_total() : 1;
+    uint4 pwh[PWN], pwl[(BF && !IO16) ? PWN : 1];
+    auto preload = [&](auto l1tag, int cidx) {
+      constexpr int L1n = decltype(l1tag)::value;
+      if constexpr (BF && L1n >= 0) {
+        const FChunk chn = chunks[cidx];
+#define E3_PRE(L2v, L3v, NTv)                                                                                   \
+  if constexpr (Slots::valid(L1n, L2v, L3v)) {                                                                  \
+    const size_t o = (size_t)(cBfoff[L3v] >> 3) + (size_t)(2 * chn.wblk[L2v][L3v] + half) * cMpad[L3v] + j;     \
+    constexpr int s0 = Slots::slot(L1n, L2v, L3v);                                                              \
+    _Pragma("unroll") for (int t = 0; t < NTv; ++t) {                                                           \
+      pwh[s0 + t] = whi_base[o + 32 * t];                                                                       \
+      if constexpr (!IO16) pwl[s0 + t] = wlo_base[o + 32 * t];                                                  \
+    }                                                                                                           \
+  }
+        E3_PRE(0, 0, NT0) E3_PRE(1, 0, NT0) E3_PRE(2, 0, NT0)
+        E3_PRE(0, 1, NT1) E3_PRE(1, 1, NT1) E3_PRE(2, 1, NT1)
+        E3_PRE(0, 2, NT2) E3_PRE(1, 2, NT2) E3_PRE(2, 2, NT2)
+#undef E3_PRE
+      }
+    };
+    preload(std::integral_constant<int, Seq::at(0)>{}, 0);
+    auto process = [&](auto itag) {
+      constexpr int L1 = Seq::at(decltype(itag)::value);
+      constexpr int L1N = Seq::at(decltype(itag)::value + 1);
       wait_vm0();
       wave_sync_lds();
       tick(1);
@@ -652,11 +775,14 @@ __global__ __launch_bounds__(256) void tp_fwd_mfma_kernel(SegArgs segs, const fl
     if (dbg & 4) {                                                                                             \
     } else if constexpr (IO16) {                                                                               \
       const size_t o = (size_t)(cBfoff[L3v] >> 3) + (size_t)(2 * ch.wblk[L2v][L3v] + half) * cMpad[L3v] + j;   \
+      static_assert(Slots::valid(L1, L2v, L3v), "path bookkeeping");                                           \
       run_steps_io16<L1, L2v, L3v, NTv>(reinterpret_cast<const uint32_t*>(xr), ch.count, whi_base + o,         \
-                                        cMpad[L3v], half, y, ACC);                                             \
+                                        pwh + Slots::slot(L1, L2v, L3v), cMpad[L3v], half, y, ACC);            \
     } else if constexpr (BF) {                                                                                 \
       const size_t o = (size_t)(cBfoff[L3v] >> 3) + (size_t)(2 * ch.wblk[L2v][L3v] + half) * cMpad[L3v] + j;   \
-      run_steps_bf<L1, L2v, L3v, NTv>(xr, ch.count, whi_base + o, wlo_base + o, cMpad[L3v], half, y, ACC);     \
+      static_assert(Slots::valid(L1, L2v, L3v), "path bookkeeping");                                           \
+      run_steps_bf<L1, L2v, L3v, NTv>(xr, ch.count, whi_base + o, wlo_base + o, pwh + Slots::slot(L1, L2v, L3v), \
+                                      pwl + Slots::slot(L1, L2v, L3v), cMpad[L3v], half, y, ACC);              \
     } else {                                                                                                   \
       const float* wp = wsrc + cWoff[L3v] + (size_t)(ch.wrow[L2v][L3v] + half) * cMpad[L3v] + j;               \
       run_steps<L1, L2v, L3v, NTv>(xr, ch.count, wp, cMpad[L3v], half, y, ACC);                                \
@@ -667,6 +793,8 @@ __global__ __launch_bounds__(256) void tp_fwd_mfma_kernel(SegArgs segs, const fl
       E3_RUN(0, 2, a2, NT2) E3_RUN(1, 2, a2, NT2) E3_RUN(2, 2, a2, NT2)
 #undef E3_RUN
       tick(3);
+      if (ci + 1 < nchunks && !(dbg & 32)) preload(std::integral_constant<int, L1N>{}, ci + 1);
+      tick(7);
       if (nbuf == 1) {
         wave_sync_lds();
         if (ci + 1 < nchunks) stage(ci + 1, cbuf);
@@ -676,7 +804,7 @@ __global__ __launch_bounds__(256) void tp_fwd_mfma_kernel(SegArgs segs, const fl
       }
       ++ci;
     };
-    (process(std::integral_constant<int, L1S>{}), ...);
+    for_each_index(process, std::make_index_sequence<sizeof...(L1S)>{});
 
     // ---- epilogue: (gate in registers,) transpose through LDS, norm + coalesced 16-byte stores ----
     // Every input chunk is consumed, so the chunk buffer becomes the out tile.  fp32 modes: one pass over the 32

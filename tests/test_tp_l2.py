@@ -173,3 +173,61 @@ def test_gpu_mfma_tp_vs_generic_kernel_large():
     with torch.no_grad():
         o32, o64 = a(x, y), b(x.double(), y.double())
     assert ((o32.double() - o64).abs().max() / o64.abs().max()).item() < 1e-5
+
+
+@pytest.mark.gpu
+def test_gpu_fused_scattered_out_blocks_vs_oracle():
+    """A 32-channel output tile whose channels belong to two irreps blocks separated by another class (scattered
+    columns): the MFMA kernel's per-channel column lookup path, checked against the fp64 oracle."""
+    from scalable_e3_gnn_amd.tensor_product import SHTensorProduct
+    torch.manual_seed(11)
+    in1, out = "8x0e+8x1o", "8x0e+8x1o+8x0e"
+    mod = SHTensorProduct(in1, out, 1).to("cuda:0")
+    assert mod.fused_supported(False)
+    B = 777
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(B, mod.in1_dim, generator=g, dtype=torch.float64)
+    y = torch.randn(B, mod.in2_dim, generator=g, dtype=torch.float64)
+    W = {c: getattr(mod, "weights_" + c).detach().double().cpu().numpy() for c in T.CLASSES if hasattr(mod, "weights_" + c)}
+    N = {c: getattr(mod, "norm_" + c).double().cpu().numpy() for c in T.CLASSES}
+    want = T.forward(in1, out, 1, x.numpy(), y.numpy(), W, N)
+    with torch.no_grad():
+        got = mod.forward_fused([(x.float().to("cuda:0"), None)], y.float().to("cuda:0"), gate=False)
+    err = np.abs(got.double().cpu().numpy() - want).max() / np.abs(want).max()
+    assert err < 1e-5, err
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("io", ["float32", "bfloat16"])
+def test_gpu_fused_unaligned_output_rows(io):
+    """C ABI called with an output whose row stride is not a multiple of 4 elements (and a ragged last tile): the
+    kernel must leave its 16-byte store path and still produce exactly the rows of the aligned call, touching
+    nothing between the rows."""
+    import ctypes
+    from scalable_e3_gnn_amd import _lib
+    from scalable_e3_gnn_amd.segnn import SEGNNLayer
+    from scalable_e3_gnn_amd.tensor_product import TPSegment
+    torch.manual_seed(5)
+    dt = getattr(torch, io)
+    layer = SEGNNLayer(32, 2).to("cuda:0").to(dt)
+    tp = layer.msg2
+    B = 32 * 5 + 7
+    g = torch.Generator(device="cuda:0").manual_seed(6)
+    m = torch.randn(B, 288, device="cuda:0", generator=g).to(dt)
+    Y = torch.randn(B, 9, device="cuda:0", generator=g)
+    with torch.no_grad():
+        ref = tp.forward_fused([(m, None)], Y, gate=True)
+    lib = _lib.load()
+    plan = tp._plan
+    ws, ns = tp._tensors()
+    packed = plan.packed(ws, ns, dt, m.device)
+    ld = 288 + 3
+    buf = torch.full((B, ld), 7.0, device="cuda:0", dtype=dt)
+    segs = (TPSegment * 1)()
+    segs[0].base, segs[0].ld, segs[0].ncols = m.data_ptr(), m.stride(0), 288
+    stream = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.e3_tp_forward_fused(plan.handle, ctypes.byref(segs), 1, Y.data_ptr(), Y.stride(0), packed.data_ptr(),
+                                       buf.data_ptr(), ld, B, _lib.dtype_code(dt), 1, stream), "e3_tp_forward_fused")
+    torch.cuda.synchronize()
+    assert torch.equal(buf[:, :288], ref)
+    assert bool((buf[:, 288:] == 7.0).all())
