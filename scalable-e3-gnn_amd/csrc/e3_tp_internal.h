@@ -57,4 +57,8 @@ int fast_forward(const TpFast* F, const e3_tp_segment* segs, int nseg, int D1, c
                  const void* packed, void* out, int64_t ldo, int64_t B, int gate, int dtype, const int32_t* ocol_tab,
                  hipStream_t s);
 
+// two-waves-per-tile kernel (e3_tp_mfma_ab.hip): 1 = launched, 0 = no instantiation / disabled, < 0 = -status
+int fast_forward_ab(const TpFast* F, const void* seg_args, const void* in2, int64_t ld2, const void* packed, void* out,
+                    int64_t ldo, int64_t B, int gate, int mode, const int32_t* ocol_tab, hipStream_t s);
+
 }  // namespace e3
