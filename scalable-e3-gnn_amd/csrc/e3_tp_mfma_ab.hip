@@ -213,11 +213,12 @@ __global__ __launch_bounds__(128, 2) void tp_fwd_mfma_ab_kernel(SegArgs segs, co
 
       float y[9];
       int ci = 0;
+      constexpr bool PRELOAD = IO16;  // fp32 storage: the 24 preload registers cost more (spills) than the exposed round trips
       constexpr int PWN = Slots::max_total();
       uint4 pwh[PWN], pwl[IO16 ? 1 : PWN];
       auto preload = [&](auto l1tag, int cidx) {
         constexpr int L1n = decltype(l1tag)::value;
-        if constexpr (L1n >= 0) {
+        if constexpr (L1n >= 0 && PRELOAD) {
           const FChunk chn = chunks[cidx];
 #define E3_PRE(L2v, L3v, NTv, T0v)                                                                              \
   if constexpr (Slots::valid(L1n, L2v, L3v)) {                                                                  \
@@ -254,6 +255,12 @@ __global__ __launch_bounds__(128, 2) void tp_fwd_mfma_ab_kernel(SegArgs segs, co
     static_assert(CG<L1, L2v, L3v>::valid, "path bookkeeping");                                                  \
     const size_t o = (size_t)(cBfoff[L3v] >> 3) + (size_t)(2 * ch.wblk[L2v][L3v] + half) * cMpad[L3v] + j +      \
                      32 * T0v;                                                                                   \
+    if constexpr (!PRELOAD) {                                                                                    \
+      _Pragma("unroll") for (int t = 0; t < NTv; ++t) {                                                          \
+        pwh[Slots::slot(L1, L2v, L3v) + t] = whi_base[o + 32 * t];                                               \
+        if constexpr (!IO16) pwl[Slots::slot(L1, L2v, L3v) + t] = wlo_base[o + 32 * t];                          \
+      }                                                                                                          \
+    }                                                                                                            \
     if (dbg & 4) {                                                                                               \
     } else if constexpr (IO16) {                                                                                 \
       run_steps_io16_lean<L1, L2v, L3v, NTv>(reinterpret_cast<const uint32_t*>(xr), ch.count, whi_base + o,           \
@@ -271,6 +278,7 @@ __global__ __launch_bounds__(128, 2) void tp_fwd_mfma_ab_kernel(SegArgs segs, co
         if (ci + 1 < nchunks) preload(std::integral_constant<int, L1N>{}, ci + 1);
         tick(7);
         __syncthreads();  // both waves are done reading the chunk
+        tick(6);          // (phase 6 = waiting for the partner wave at this barrier)
         if (ci + 1 < nchunks) stage(ci + 1, cbuf);
         tick(2);
         ++ci;
@@ -406,7 +414,8 @@ __global__ __launch_bounds__(128, 2) void tp_fwd_mfma_ab_kernel(SegArgs segs, co
   };
   if (wave == 0) body(std::integral_constant<int, 0>{});
   else body(std::integral_constant<int, 1>{});
-  if (prof && lane == 0)
+  // E3_TP_DBG & 128 / & 256: only wave B / only wave A reports (per-role phase shares)
+  if (prof && lane == 0 && !((dbg & 128) && wave == 0) && !((dbg & 256) && wave == 1))
     for (int q = 0; q < 8; ++q) atomicAdd(&prof[q], tacc[q]);
 }
 

@@ -51,5 +51,5 @@ if int(os.environ.get("E3_TP_DBG", "0")) & 8:
             call()
         lib.e3_tp_debug_phase_cycles(plan.handle, buf)
         tot = sum(buf)
-        print(name, "phase shares: prologue %.1f%% wait %.1f%% stage-issue %.1f%% runs %.1f%% epi-transpose %.1f%% epi-store %.1f%% [stage-setup %.1f%% w-preload %.1f%%]" % tuple(100.0 * b / tot for b in list(buf)[:8]),
+        print(name, "phase shares: prologue %.1f%% wait %.1f%% stage-issue %.1f%% runs %.1f%% epi-transpose %.1f%% epi-store %.1f%% [stage-setup|partner-wait %.1f%% w-preload %.1f%%]" % tuple(100.0 * b / tot for b in list(buf)[:8]),
               " cycles/tile-wave %.0f" % (tot / (E / 32)))
