@@ -62,6 +62,8 @@ SIGNATURES = {
     "e3_tp_forward_fused": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64,
                                     c_int, c_int, c_void_p]),
     "e3_tp_fused_supported": (c_int, [c_void_p, c_int]),
+    "e3_tp_forward_fused_scatter": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
+                                            c_int64, c_int64, c_int, c_int, c_void_p]),
     "e3_tp_debug_phase_cycles": (c_int, [c_void_p, c_void_p]),
     "e3_segment_sum_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p]),
     "e3_edge_geometry_l2": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -375,6 +375,19 @@ int e3_tp_forward_fused(const e3_tp_plan* plan, const e3_tp_segment* segs, int n
                       out, ldo, B, gate, dtype, plan->dev.ocol, (hipStream_t)stream);
 }
 
+int e3_tp_forward_fused_scatter(const e3_tp_plan* plan, const e3_tp_segment* segs, int nseg, const void* in2,
+                                int64_t ld2, const void* packed, const int32_t* row_node, void* out_nodes,
+                                int64_t ldo, int64_t B, int dtype, int gate, void* stream) {
+  if (!plan || !segs || !row_node || B < 0) return E3_ERR_INVALID_ARG;
+  if (dtype != E3_F32 || !gate || !plan->fast.usable || ld2 == 0) return E3_ERR_UNSUPPORTED;
+  if (B == 0) return E3_OK;
+  if (!in2 || !packed || !out_nodes || ld2 < plan->dev.Dy) return E3_ERR_INVALID_ARG;
+  int st = tp_ensure_device(plan);
+  if (st != E3_OK) return st;
+  return fast_forward(&plan->fast, segs, nseg, plan->dev.D1, in2, ld2, (const char*)packed + fast_section_offset(plan),
+                      out_nodes, ldo, B, gate, dtype, plan->dev.ocol, (hipStream_t)stream, row_node);
+}
+
 // diagnostic: per-phase wave-cycle sums of the MFMA kernel (E3_TP_DBG & 8); reads and clears
 int e3_tp_debug_phase_cycles(const e3_tp_plan* plan, unsigned long long out[8]) {
   if (!plan || !out || !plan->fast.dev.prof) return E3_ERR_UNSUPPORTED;

@@ -55,7 +55,7 @@ int fast_pack(const TpFast* F, const void* const w[6], const void* const n[6], i
               const int32_t* ocol_tab, hipStream_t s);
 int fast_forward(const TpFast* F, const e3_tp_segment* segs, int nseg, int D1, const void* in2, int64_t ld2,
                  const void* packed, void* out, int64_t ldo, int64_t B, int gate, int dtype, const int32_t* ocol_tab,
-                 hipStream_t s);
+                 hipStream_t s, const int32_t* scatter = nullptr);
 
 // two-waves-per-tile kernel (e3_tp_mfma_ab.hip): 1 = launched, 0 = no instantiation / disabled, < 0 = -status
 int fast_forward_ab(const TpFast* F, const void* seg_args, const void* in2, int64_t ld2, const void* packed, void* out,

@@ -698,7 +698,7 @@ int fast_pack(const TpFast* F, const void* const w[6], const void* const n[6], i
 
 int fast_forward(const TpFast* F, const e3_tp_segment* segs, int nseg, int D1, const void* in2, int64_t ld2,
                  const void* packed, void* out, int64_t ldo, int64_t B, int gate, int dtype, const int32_t* ocol_tab,
-                 hipStream_t s) {
+                 hipStream_t s, const int32_t* scatter) {
   if (!F->usable) return E3_ERR_UNSUPPORTED;
   const bool io16 = dtype == E3_BF16;
   const FDev& d = io16 ? F->dev16 : F->dev;
@@ -719,6 +719,7 @@ int fast_forward(const TpFast* F, const e3_tp_segment* segs, int nseg, int D1, c
   }
   for (int i = nseg; i < 5; ++i) sa.col0[i] = col;
   sa.nseg = nseg;
+  sa.scatter = scatter;
   if (col != D1) return E3_ERR_INVALID_ARG;
   for (auto& ch : F->h_chunks) {  // a chunk must not straddle two segments
     int cw = ch.count * (2 * ch.l1 + 1), sidx = 0;
@@ -735,6 +736,7 @@ int fast_forward(const TpFast* F, const e3_tp_segment* segs, int nseg, int D1, c
     const int r = fast_forward_ab(F, &sa, in2, ld2, packed, out, ldo, B, gate, mode, ocol_tab, s);
     if (r == 1) return E3_OK;
     if (r < 0) return -r;
+    if (scatter) return E3_ERR_UNSUPPORTED;  // only the two-wave kernel has the fused segment-sum
   }
   std::vector<int> l1s;
   for (auto& c : F->h_chunks) l1s.push_back(c.l1);

@@ -39,13 +39,16 @@ struct RoleSplit {
   }
 };
 
-template <int LSH, int NT0, int NT1, int NT2, bool GATE, int MODE, int... L1S>
+// SCAT: rows are not stored but summed per node id (segs.scatter, ascending) into out[node] with fp32 atomics --
+// the segment-sum of the message pass fused into the epilogue (the [E, width] messages never reach HBM)
+template <int LSH, int NT0, int NT1, int NT2, bool GATE, int MODE, bool SCAT, int... L1S>
 __global__ __launch_bounds__(128, 2) void tp_fwd_mfma_ab_kernel(SegArgs segs, const float* __restrict__ in2, int64_t ld2,
                                                                  const float* __restrict__ packed, void* __restrict__ outv,
                                                                  int64_t ldo, int64_t B, const FDev* __restrict__ dp,
                                                                  const FChunk* __restrict__ chunks,
                                                                  const int32_t* __restrict__ ocol_tab) {
   static_assert(MODE == 1 || MODE == 2, "bf16-pipe modes only");
+  static_assert(!SCAT || MODE == 1, "fused scatter: fp32 storage only (fp32 atomics)");
   constexpr bool IO16 = MODE == 2;
   constexpr int CHUNK = IO16 ? kChunk16 : kChunkFloats;
   using RS = RoleSplit<NT0, NT1, NT2, GATE>;
@@ -116,6 +119,10 @@ __global__ __launch_bounds__(128, 2) void tp_fwd_mfma_ab_kernel(SegArgs segs, co
       const int nrows = (int)((B - row0) < 32 ? (B - row0) : 32);
       mc0 = mn0; mc1 = mn1; mc2 = mn2; mc3 = mn3;
       if (tile + tstride < ntiles) fetch_ids(tile + tstride);
+      int sd = -1;  // SCAT: node id of this lane's row (lane & 31), -1 beyond the batch
+      if constexpr (SCAT) {
+        if (j < nrows) sd = segs.scatter[row0 + j];
+      }
 
       // stage this wave's half of chunk ci (batches of rows alternate between the two waves)
       auto stage = [&](int ci, float* dst) {
@@ -307,7 +314,32 @@ __global__ __launch_bounds__(128, 2) void tp_fwd_mfma_ab_kernel(SegArgs segs, co
             for (int c = 0; c < D; ++c) ot[j * TS + D * (chan_of(ps * RPP + r) - ps * NCH) + c] = val(ps * RPP + r, c);
           wave_sync_lds();
           tick(4);
-          if (vec) {
+          if constexpr (SCAT) {
+            // lane = column of this pass: running sum over the 32 rows, flushed with one fp32 atomic per lane whenever
+            // the node id changes (ids ascend: a run is contiguous) and at the end.  The node ids are wave-uniform
+            // (v_readlane), so the row loop is scalar control flow around one LDS read and one FMA; an atomic
+            // instruction covers up to 64 consecutive floats of one node row.
+            for (int cb = 0; cb < NCH * D; cb += 64) {
+              const int lc = cb + lane, glc = ps * NCH * D + lc;
+              const bool cok = lc < NCH * D && glc < width;
+              const float nv = cok ? (ncolb >= 0 ? nrm[ncolb + glc] : 1.f) : 0.f;
+              float* const obase = reinterpret_cast<float*>(outv) + colb + glc;
+              const float* src = ot + (cok ? lc : 0);
+              float acc = 0.f;
+              int cur = -1;
+#pragma unroll 8
+              for (int r = 0; r < 32; ++r) {
+                const int dn = __builtin_amdgcn_readlane(sd, r);
+                if (dn != cur) {
+                  if (cur >= 0 && cok && !(dbg & 1)) __builtin_amdgcn_global_atomic_fadd_f32(obase + (int64_t)cur * ldo, acc);
+                  acc = 0.f;
+                  cur = dn;
+                }
+                if (dn >= 0) acc = __builtin_fmaf(src[r * TS], nv, acc);
+              }
+              if (cur >= 0 && cok && !(dbg & 1)) __builtin_amdgcn_global_atomic_fadd_f32(obase + (int64_t)cur * ldo, acc);
+            }
+          } else if (vec) {
             constexpr uint32_t INV = (65536 + UPR - 1) / UPR;
             static_assert(((32u * UPR - 1) * INV >> 16) == 31 && ((31u * UPR) * INV >> 16) == 31 &&
                           ((30u * UPR + UPR - 1) * INV >> 16) == 30, "reciprocal");
@@ -426,19 +458,21 @@ struct AbKernelEntry {
   int lsh, nt0, nt1, nt2;
   std::vector<int> l1s;
   const void* fn[2][2];  // [mode - 1][gate]
+  const void* fn_scat;   // fp32 storage, gated, fused segment-sum (nullptr = not instantiated)
 };
-#define E3_AB(LSH, a, b, c, ...)                                                                             \
+#define E3_AB(LSH, a, b, c, SC, ...)                                                                          \
   {LSH, a, b, c, {__VA_ARGS__},                                                                               \
-   {{(const void*)tp_fwd_mfma_ab_kernel<LSH, a, b, c, false, 1, __VA_ARGS__>,                                  \
-     (const void*)tp_fwd_mfma_ab_kernel<LSH, a, b, c, true, 1, __VA_ARGS__>},                                  \
-    {(const void*)tp_fwd_mfma_ab_kernel<LSH, a, b, c, false, 2, __VA_ARGS__>,                                  \
-     (const void*)tp_fwd_mfma_ab_kernel<LSH, a, b, c, true, 2, __VA_ARGS__>}}}
+   {{(const void*)tp_fwd_mfma_ab_kernel<LSH, a, b, c, false, 1, false, __VA_ARGS__>,                           \
+     (const void*)tp_fwd_mfma_ab_kernel<LSH, a, b, c, true, 1, false, __VA_ARGS__>},                           \
+    {(const void*)tp_fwd_mfma_ab_kernel<LSH, a, b, c, false, 2, false, __VA_ARGS__>,                           \
+     (const void*)tp_fwd_mfma_ab_kernel<LSH, a, b, c, true, 2, false, __VA_ARGS__>}},                          \
+   SC ? (const void*)tp_fwd_mfma_ab_kernel<LSH, a, b, c, true, 1, SC, __VA_ARGS__> : nullptr}
 static const std::vector<AbKernelEntry>& ab_kernels() {
   static const std::vector<AbKernelEntry> k = {
-      E3_AB(2, 3, 1, 1, 0, 1, 2, 0, 1, 2, 0),  // message TP #1
-      E3_AB(2, 3, 1, 1, 0, 1, 2),              // message TP #2
+      E3_AB(2, 3, 1, 1, false, 0, 1, 2, 0, 1, 2, 0),  // message TP #1
+      E3_AB(2, 3, 1, 1, true, 0, 1, 2),               // message TP #2 (+ fused segment-sum)
 #ifndef E3_TP_SUBSET
-      E3_AB(2, 3, 1, 1, 0, 1, 2, 0, 1, 2),     // update TP #1
+      E3_AB(2, 3, 1, 1, false, 0, 1, 2, 0, 1, 2),     // update TP #1
 #endif
   };
   return k;
@@ -452,6 +486,7 @@ static bool ab_enabled() {
 // 1 = launched, 0 = not applicable (caller uses the one-wave kernel), < 0 = -status
 int fast_forward_ab(const TpFast* F, const void* sa_, const void* in2, int64_t ld2, const void* packed, void* out,
                     int64_t ldo, int64_t B, int gate, int mode, const int32_t* ocol_tab, hipStream_t s) {
+  const bool scat = static_cast<const SegArgs*>(sa_)->scatter != nullptr;
   if (!ab_enabled() || mode < 1) return 0;
   const FDev& d = mode == 2 ? F->dev16 : F->dev;
   std::vector<int> l1s;
@@ -460,7 +495,8 @@ int fast_forward_ab(const TpFast* F, const void* sa_, const void* in2, int64_t l
   for (auto& k : ab_kernels())
     if (k.lsh == d.lsh && k.nt0 == d.NT[0] && k.nt1 == d.NT[1] && k.nt2 == d.NT[2] && k.l1s == l1s) e = &k;
   if (!e) return 0;
-  const void* fn = e->fn[mode - 1][gate ? 1 : 0];
+  if (scat && (mode != 1 || !gate || !e->fn_scat || (ldo & 3) || (reinterpret_cast<uintptr_t>(out) & 15))) return 0;
+  const void* fn = scat ? e->fn_scat : e->fn[mode - 1][gate ? 1 : 0];
   const size_t lds_bytes = (size_t)(((d.Dout + 4 + 15) & ~15) + ((d.ntab + 15) & ~15) +
                                     (mode == 2 ? kChunk16 : kChunkFloats) + 320) * 4;
   static std::vector<const void*> configured;

@@ -648,6 +648,7 @@ struct SegArgs {
   const int32_t* index[4];
   int col0[5];  // first in1 column of each segment; col0[nseg] = D1
   int nseg;
+  const int32_t* scatter;  // fused segment-sum (e3_tp_forward_fused_scatter): node id of every row, ascending; else null
 };
 
 __device__ __forceinline__ float sigmoid_(float v) { return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }

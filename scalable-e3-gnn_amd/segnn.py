@@ -19,6 +19,8 @@ Every TP is the reference operator (`L1TensorProduct`), i.e. the pinned hot path
 """
 from __future__ import annotations
 
+import os
+
 import torch
 from torch import nn
 
@@ -48,6 +50,8 @@ class SEGNNLayer(nn.Module):
         hid, gated = _hidden_irreps(H, lmax)
         self.H, self.lmax = H, lmax
         self.fused = True  # use the fused gather+TP+gate kernel when the shapes allow it
+        # fused segment-sum (atomics: sums agree to fp32 rounding, not bit for bit); E3_FUSED_SCATTER=0 disables
+        self.fuse_scatter = os.environ.get("E3_FUSED_SCATTER", "1") != "0"
         self.msg1 = _make_tp(hid + hid + Irreps("1x0e"), gated, lmax)
         self.msg2 = _make_tp(hid, gated, lmax)
         self.upd1 = _make_tp(hid + hid, gated, lmax)
@@ -73,8 +77,14 @@ class SEGNNLayer(nn.Module):
             if d.dtype != h.dtype:
                 d = d.to(h.dtype)
             m = self.msg1.forward_fused([(h, g.dst), (h, g.src), (d, None)], Y, gate=True)
-            m = self.msg2.forward_fused([(m, None)], Y, gate=True)
-            a = ops.segment_sum(m, g)
+            # message TP #2 with the segment-sum fused into its epilogue where the library has that kernel (fp32
+            # storage, l_max = 2): the [E, width] messages are never written; otherwise two kernels
+            a = None
+            if self.fuse_scatter and m.dtype == torch.float32:
+                a = self.msg2.forward_fused([(m, None)], Y, gate=True, scatter=(g.dst, g.rowptr.numel() - 1))
+            if a is None:
+                m = self.msg2.forward_fused([(m, None)], Y, gate=True)
+                a = ops.segment_sum(m, g)
             u = self.upd1.forward_fused([(h, None), (a, None)], A, gate=True)
             u = self.upd2(u, A)
             return h + u

@@ -92,8 +92,10 @@ class TPPlan:
         self._packed, self._key = packed, key
         return packed
 
-    def forward_fused(self, ws, ns, segments, in2, gate: bool, tag=""):
-        """segments: [(tensor [R, ncols] fp32, row_index int32 [B] | None), ...]; -> [B, out_dim or gated width]"""
+    def forward_fused(self, ws, ns, segments, in2, gate: bool, tag="", scatter=None):
+        """segments: [(tensor [R, ncols] fp32, row_index int32 [B] | None), ...]; -> [B, out_dim or gated width].
+        scatter = (row_node int32 [B] ascending, n_nodes): rows are summed per node instead of stored (fused
+        segment-sum, fp32 atomics) -> [n_nodes, width]; returns None when the library has no such kernel for this plan."""
         lib = _lib.load()
         B = in2.shape[0]
         dev = in2.device
@@ -124,7 +126,14 @@ class TPPlan:
             width = {160: 128, 352: 288, 224: 192}.get(self.out_dim)
             if width is None:
                 raise RuntimeError("gate fusion needs out irreps [32x0e | 32x0e per block | 32x1o | 32x2e]")
-        out = torch.empty((B, width), dtype=io, device=dev)
+        if scatter is not None:
+            row_node, n_nodes = scatter
+            if io != torch.float32 or not gate:
+                return None
+            assert row_node.dtype == torch.int32 and row_node.numel() == B and row_node.is_cuda
+            out = torch.zeros((n_nodes, width), dtype=io, device=dev)
+        else:
+            out = torch.empty((B, width), dtype=io, device=dev)
         if B == 0:
             return out
         if in2.stride(-1) != 1:
@@ -134,16 +143,25 @@ class TPPlan:
             packed = self.packed(ws, ns, io, dev)
             stream = torch.cuda.current_stream(dev).cuda_stream
             t0 = profiling.begin() if profiling.enabled() else None
-            _lib.check(lib.e3_tp_forward_fused(self.handle, ctypes.byref(segs), len(segments), in2.data_ptr(),
-                                               in2.stride(0), packed.data_ptr(), out.data_ptr(), out.stride(0), B,
-                                               _lib.dtype_code(io), 1 if gate else 0, stream), "e3_tp_forward_fused")
+            if scatter is not None:
+                st = lib.e3_tp_forward_fused_scatter(self.handle, ctypes.byref(segs), len(segments), in2.data_ptr(),
+                                                     in2.stride(0), packed.data_ptr(), scatter[0].data_ptr(),
+                                                     out.data_ptr(), out.stride(0), B, _lib.dtype_code(io), 1, stream)
+                if st == 4:  # E3_ERR_UNSUPPORTED: no fused-scatter kernel for this plan / build
+                    return None
+                _lib.check(st, "e3_tp_forward_fused_scatter")
+            else:
+                _lib.check(lib.e3_tp_forward_fused(self.handle, ctypes.byref(segs), len(segments), in2.data_ptr(),
+                                                   in2.stride(0), packed.data_ptr(), out.data_ptr(), out.stride(0), B,
+                                                   _lib.dtype_code(io), 1 if gate else 0, stream), "e3_tp_forward_fused")
             if t0 is not None:
                 # algorithmic bytes: gathered segments count their SOURCE rows once (re-gathers are cache traffic)
                 nb = sum((t.shape[0] * t.shape[1] * esz + (4 * B if idx is not None else 0)) for t, idx in
-                         [(k, s[1]) for k, s in zip(keep, segments)]) + (4 * self.in2_dim + esz * width) * B
+                         [(k, s[1]) for k, s in zip(keep, segments)]) + 4 * self.in2_dim * B + \
+                     (esz * width * B if scatter is None else 4 * B + esz * width * scatter[1])
                 mode = ("<bf16 storage, bf16 MFMA>" if io == torch.bfloat16 else
                         "<exact fp32 MFMA>" if os.environ.get("E3_TP_EXACT") else "<bf16x3 split MFMA>")
-                profiling.end(f"tp_fused {tag} B={B}", B, nb, t0, flops=self.flops_per_row * B,
+                profiling.end(f"tp_fused{'+segsum' if scatter is not None else ''} {tag} B={B}", B, nb, t0, flops=self.flops_per_row * B,
                               kernel="e3::tp_fwd_mfma_kernel" + mode)
         return out
 
@@ -180,10 +198,11 @@ class SHTensorProduct(nn.Module):
     def fused_supported(self, gate: bool) -> bool:
         return self._plan.fused_supported(gate)
 
-    def forward_fused(self, segments, in2, gate: bool = False):
-        """TP over ``in1 = [seg0[idx0] | seg1[idx1] | ...]`` (gather + concat fused), optional fused gate."""
+    def forward_fused(self, segments, in2, gate: bool = False, scatter=None):
+        """TP over ``in1 = [seg0[idx0] | seg1[idx1] | ...]`` (gather + concat fused), optional fused gate, optional
+        fused segment-sum (``scatter=(row_node, n_nodes)``, see ``TPPlan.forward_fused``; None = unsupported)."""
         ws, ns = self._tensors()
-        return self._plan.forward_fused(ws, ns, segments, in2, gate, tag=f"{self.iri1}->{self.iro}")
+        return self._plan.forward_fused(ws, ns, segments, in2, gate, tag=f"{self.iri1}->{self.iro}", scatter=scatter)
 
     def forward(self, in1: torch.Tensor, in2: torch.Tensor) -> torch.Tensor:
         torch._assert(in1.shape[-1] == self.in1_dim,

@@ -130,3 +130,33 @@ def test_segnn_lmax2_fused_H32_vs_oracle():
     want = S.forward_l2(params, H, L, "1x0e+1x1o", "1x1o", xs.double().numpy(), pos.numpy()[perm],
                         g.rowptr.cpu().numpy(), g.src.cpu().numpy())
     assert rel(out, want) < 1e-4, rel(out, want)
+
+
+@pytest.mark.gpu
+def test_fused_segment_sum_matches_two_kernels():
+    """e3_tp_forward_fused_scatter (message TP #2 with the segment-sum in its epilogue, fp32 atomics) vs
+    e3_tp_forward_fused + e3_segment_sum: equal to fp32 rounding of the sums (the order of the atomics is not fixed)."""
+    import torch
+    from scalable_e3_gnn_amd import ops
+    from scalable_e3_gnn_amd.radius_graph import radius_graph
+    from scalable_e3_gnn_amd.segnn import SEGNNLayer
+    torch.manual_seed(21)
+    dev = "cuda:0"
+    N = 3000
+    pos = torch.rand(N, 3, device=dev)
+    g = radius_graph(pos, 0.12, [0, 0, 0], [1, 1, 1])
+    E = g.num_edges
+    assert E % 32 != 0 or True
+    layer = SEGNNLayer(32, 2).to(dev)
+    m = torch.randn(E, 288, device=dev)
+    Y = torch.randn(E, 9, device=dev)
+    with torch.no_grad():
+        ref = ops.segment_sum(layer.msg2.forward_fused([(m, None)], Y, gate=True), g)
+        got = layer.msg2.forward_fused([(m, None)], Y, gate=True, scatter=(g.dst, N))
+    assert got is not None, "fused scatter kernel missing for the l_max=2 message product"
+    assert got.shape == ref.shape
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 1e-5, err
+    # nodes without edges stay exactly zero
+    deg = (g.rowptr[1:] - g.rowptr[:-1])
+    assert bool((got[deg == 0] == 0).all())
