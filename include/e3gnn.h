@@ -230,8 +230,9 @@ int e3_tp_fused_supported(const e3_tp_plan* plan, int gate);
  * stored but ADDED to out_nodes[row_node[b]] (fp32 atomics; row_node ascending, e.g. the dst column of a CSR-by-dst
  * edge list; out_nodes zero-initialised by the caller, ld_out a multiple of 4 elements, 16-byte aligned).  The
  * [B, width] messages never reach HBM.  Summation order is not fixed: results agree with e3_tp_forward_fused +
- * e3_segment_sum to fp32 rounding of the sum, not bit for bit.  fp32 storage, gate = 1 only; E3_ERR_UNSUPPORTED when
- * the plan has no two-wave instantiation with this epilogue (callers then run the two kernels). */
+ * e3_segment_sum to fp32 rounding of the sum, not bit for bit.  out_nodes is FP32 for both storage types (`dtype` is
+ * the storage of the inputs; with E3_BF16 the caller rounds the sums once).  gate = 1 only; E3_ERR_UNSUPPORTED when the
+ * plan has no two-wave instantiation with this epilogue (callers then run the two kernels). */
 int e3_tp_forward_fused_scatter(const e3_tp_plan* plan, const e3_tp_segment* segs, int nseg,
                                 const void* in2, int64_t ld_in2, const void* packed, const int32_t* row_node,
                                 void* out_nodes, int64_t ld_out, int64_t B, int dtype, int gate, void* stream);

@@ -379,7 +379,7 @@ int e3_tp_forward_fused_scatter(const e3_tp_plan* plan, const e3_tp_segment* seg
                                 int64_t ld2, const void* packed, const int32_t* row_node, void* out_nodes,
                                 int64_t ldo, int64_t B, int dtype, int gate, void* stream) {
   if (!plan || !segs || !row_node || B < 0) return E3_ERR_INVALID_ARG;
-  if (dtype != E3_F32 || !gate || !plan->fast.usable || ld2 == 0) return E3_ERR_UNSUPPORTED;
+  if ((dtype != E3_F32 && dtype != E3_BF16) || !gate || !plan->fast.usable || ld2 == 0) return E3_ERR_UNSUPPORTED;
   if (B == 0) return E3_OK;
   if (!in2 || !packed || !out_nodes || ld2 < plan->dev.Dy) return E3_ERR_INVALID_ARG;
   int st = tp_ensure_device(plan);

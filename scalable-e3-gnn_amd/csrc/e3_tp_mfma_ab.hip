@@ -39,7 +39,8 @@ struct RoleSplit {
   }
 };
 
-// SCAT: rows are not stored but summed per node id (segs.scatter, ascending) into out[node] with fp32 atomics --
+// SCAT: rows are not stored but summed per node id (segs.scatter, ascending) into the FP32 array out[node] (also for
+// bf16 storage: the caller rounds the sums once) with fp32 atomics --
 // the segment-sum of the message pass fused into the epilogue (the [E, width] messages never reach HBM)
 template <int LSH, int NT0, int NT1, int NT2, bool GATE, int MODE, bool SCAT, int... L1S>
 __global__ __launch_bounds__(128, 2) void tp_fwd_mfma_ab_kernel(SegArgs segs, const float* __restrict__ in2, int64_t ld2,
@@ -48,7 +49,6 @@ __global__ __launch_bounds__(128, 2) void tp_fwd_mfma_ab_kernel(SegArgs segs, co
                                                                  const FChunk* __restrict__ chunks,
                                                                  const int32_t* __restrict__ ocol_tab) {
   static_assert(MODE == 1 || MODE == 2, "bf16-pipe modes only");
-  static_assert(!SCAT || MODE == 1, "fused scatter: fp32 storage only (fp32 atomics)");
   constexpr bool IO16 = MODE == 2;
   constexpr int CHUNK = IO16 ? kChunk16 : kChunkFloats;
   using RS = RoleSplit<NT0, NT1, NT2, GATE>;
@@ -458,7 +458,7 @@ struct AbKernelEntry {
   int lsh, nt0, nt1, nt2;
   std::vector<int> l1s;
   const void* fn[2][2];  // [mode - 1][gate]
-  const void* fn_scat;   // fp32 storage, gated, fused segment-sum (nullptr = not instantiated)
+  const void* fn_scat[2];  // [mode - 1]: gated, fused segment-sum into an fp32 node array (nullptr = not instantiated)
 };
 #define E3_AB(LSH, a, b, c, SC, ...)                                                                          \
   {LSH, a, b, c, {__VA_ARGS__},                                                                               \
@@ -466,7 +466,8 @@ struct AbKernelEntry {
      (const void*)tp_fwd_mfma_ab_kernel<LSH, a, b, c, true, 1, false, __VA_ARGS__>},                           \
     {(const void*)tp_fwd_mfma_ab_kernel<LSH, a, b, c, false, 2, false, __VA_ARGS__>,                           \
      (const void*)tp_fwd_mfma_ab_kernel<LSH, a, b, c, true, 2, false, __VA_ARGS__>}},                          \
-   SC ? (const void*)tp_fwd_mfma_ab_kernel<LSH, a, b, c, true, 1, SC, __VA_ARGS__> : nullptr}
+   {SC ? (const void*)tp_fwd_mfma_ab_kernel<LSH, a, b, c, true, 1, SC, __VA_ARGS__> : nullptr,                 \
+    nullptr /* bf16 storage: measured slower than the two kernels (4 narrow passes per tile), not instantiated */}}
 static const std::vector<AbKernelEntry>& ab_kernels() {
   static const std::vector<AbKernelEntry> k = {
       E3_AB(2, 3, 1, 1, false, 0, 1, 2, 0, 1, 2, 0),  // message TP #1
@@ -495,8 +496,8 @@ int fast_forward_ab(const TpFast* F, const void* sa_, const void* in2, int64_t l
   for (auto& k : ab_kernels())
     if (k.lsh == d.lsh && k.nt0 == d.NT[0] && k.nt1 == d.NT[1] && k.nt2 == d.NT[2] && k.l1s == l1s) e = &k;
   if (!e) return 0;
-  if (scat && (mode != 1 || !gate || !e->fn_scat || (ldo & 3) || (reinterpret_cast<uintptr_t>(out) & 15))) return 0;
-  const void* fn = scat ? e->fn_scat : e->fn[mode - 1][gate ? 1 : 0];
+  if (scat && (!gate || !e->fn_scat[mode - 1])) return 0;
+  const void* fn = scat ? e->fn_scat[mode - 1] : e->fn[mode - 1][gate ? 1 : 0];
   const size_t lds_bytes = (size_t)(((d.Dout + 4 + 15) & ~15) + ((d.ntab + 15) & ~15) +
                                     (mode == 2 ? kChunk16 : kChunkFloats) + 320) * 4;
   static std::vector<const void*> configured;

@@ -77,10 +77,9 @@ class SEGNNLayer(nn.Module):
             if d.dtype != h.dtype:
                 d = d.to(h.dtype)
             m = self.msg1.forward_fused([(h, g.dst), (h, g.src), (d, None)], Y, gate=True)
-            # message TP #2 with the segment-sum fused into its epilogue where the library has that kernel (fp32
-            # storage, l_max = 2): the [E, width] messages are never written; otherwise two kernels
+            # message TP #2 with the segment-sum fused into its epilogue where the library has that kernel (l_max = 2): the [E, width] messages are never written; otherwise two kernels
             a = None
-            if self.fuse_scatter and m.dtype == torch.float32:
+            if self.fuse_scatter:
                 a = self.msg2.forward_fused([(m, None)], Y, gate=True, scatter=(g.dst, g.rowptr.numel() - 1))
             if a is None:
                 m = self.msg2.forward_fused([(m, None)], Y, gate=True)

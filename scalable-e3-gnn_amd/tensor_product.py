@@ -128,10 +128,10 @@ class TPPlan:
                 raise RuntimeError("gate fusion needs out irreps [32x0e | 32x0e per block | 32x1o | 32x2e]")
         if scatter is not None:
             row_node, n_nodes = scatter
-            if io != torch.float32 or not gate:
+            if not gate:
                 return None
             assert row_node.dtype == torch.int32 and row_node.numel() == B and row_node.is_cuda
-            out = torch.zeros((n_nodes, width), dtype=io, device=dev)
+            out = torch.zeros((n_nodes, width), dtype=torch.float32, device=dev)  # fp32 sums for both storage types
         else:
             out = torch.empty((B, width), dtype=io, device=dev)
         if B == 0:
@@ -150,6 +150,8 @@ class TPPlan:
                 if st == 4:  # E3_ERR_UNSUPPORTED: no fused-scatter kernel for this plan / build
                     return None
                 _lib.check(st, "e3_tp_forward_fused_scatter")
+                if io != torch.float32:
+                    out = out.to(io)  # one rounding of the fp32 sums (what e3_segment_sum_bf16 does)
             else:
                 _lib.check(lib.e3_tp_forward_fused(self.handle, ctypes.byref(segs), len(segments), in2.data_ptr(),
                                                    in2.stride(0), packed.data_ptr(), out.data_ptr(), out.stride(0), B,
@@ -158,7 +160,7 @@ class TPPlan:
                 # algorithmic bytes: gathered segments count their SOURCE rows once (re-gathers are cache traffic)
                 nb = sum((t.shape[0] * t.shape[1] * esz + (4 * B if idx is not None else 0)) for t, idx in
                          [(k, s[1]) for k, s in zip(keep, segments)]) + 4 * self.in2_dim * B + \
-                     (esz * width * B if scatter is None else 4 * B + esz * width * scatter[1])
+                     (esz * width * B if scatter is None else 4 * B + 4 * width * scatter[1])
                 mode = ("<bf16 storage, bf16 MFMA>" if io == torch.bfloat16 else
                         "<exact fp32 MFMA>" if os.environ.get("E3_TP_EXACT") else "<bf16x3 split MFMA>")
                 profiling.end(f"tp_fused{'+segsum' if scatter is not None else ''} {tag} B={B}", B, nb, t0, flops=self.flops_per_row * B,

@@ -133,30 +133,56 @@ def test_segnn_lmax2_fused_H32_vs_oracle():
 
 
 @pytest.mark.gpu
-def test_fused_segment_sum_matches_two_kernels():
+def test_segnn_lmax1_fused_H32_vs_oracle():
+    """l_max = 1, H = 32 under no_grad: the fused path on the reference operator's plans (one-wave MFMA kernel, no
+    fused segment-sum instantiation -> the scatter request must fall back to the two kernels)."""
+    N, H, L = 400, 32, 2
+    torch.manual_seed(12)
+    pos = torch.rand(N, 3, generator=torch.Generator().manual_seed(12))
+    r = float((3 * 10.0 / (4 * np.pi * N)) ** (1 / 3))
+    model = SEGNN("1x0e+1x1o", H, "1x1o", L, lmax=1).to(DEV)
+    g = radius_graph(pos.to(DEV), r, [0, 0, 0], [1, 1, 1])
+    xs = torch.randn(N, 4, generator=torch.Generator().manual_seed(13))[g.perm.cpu().long()]
+    with torch.no_grad():
+        assert model.layers[0]._fused()
+        out = model(xs.to(DEV), g)
+    params = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    perm = g.perm.cpu().numpy()
+    want = S.forward(params, H, L, "1x0e+1x1o", "1x1o", xs.double().numpy(), pos.numpy()[perm],
+                     g.rowptr.cpu().numpy(), g.src.cpu().numpy())
+    assert rel(out, want) < 1e-4, rel(out, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("io", ["float32", "bfloat16"])
+def test_fused_segment_sum_matches_two_kernels(io):
     """e3_tp_forward_fused_scatter (message TP #2 with the segment-sum in its epilogue, fp32 atomics) vs
-    e3_tp_forward_fused + e3_segment_sum: equal to fp32 rounding of the sums (the order of the atomics is not fixed)."""
+    e3_tp_forward_fused + e3_segment_sum: equal to fp32 rounding of the sums (the order of the atomics is not fixed);
+    bf16 storage: the two-kernel path rounds every message to bf16 before summing, the fused one does not, so they
+    agree to bf16 resolution of the messages."""
     import torch
     from scalable_e3_gnn_amd import ops
     from scalable_e3_gnn_amd.radius_graph import radius_graph
     from scalable_e3_gnn_amd.segnn import SEGNNLayer
     torch.manual_seed(21)
     dev = "cuda:0"
+    dt = getattr(torch, io)
     N = 3000
     pos = torch.rand(N, 3, device=dev)
     g = radius_graph(pos, 0.12, [0, 0, 0], [1, 1, 1])
     E = g.num_edges
-    assert E % 32 != 0 or True
-    layer = SEGNNLayer(32, 2).to(dev)
-    m = torch.randn(E, 288, device=dev)
+    layer = SEGNNLayer(32, 2).to(dev).to(dt)
+    m = torch.randn(E, 288, device=dev).to(dt)
     Y = torch.randn(E, 9, device=dev)
     with torch.no_grad():
         ref = ops.segment_sum(layer.msg2.forward_fused([(m, None)], Y, gate=True), g)
         got = layer.msg2.forward_fused([(m, None)], Y, gate=True, scatter=(g.dst, N))
+    if io == "bfloat16" and got is None:
+        pytest.skip("fused segment-sum is not instantiated for bf16 storage (slower than the two kernels)")
     assert got is not None, "fused scatter kernel missing for the l_max=2 message product"
-    assert got.shape == ref.shape
-    err = (got - ref).abs().max().item() / ref.abs().max().item()
-    assert err < 1e-5, err
+    assert got.shape == ref.shape and got.dtype == ref.dtype
+    err = (got.float() - ref.float()).abs().max().item() / ref.float().abs().max().item()
+    assert err < (1e-5 if io == "float32" else 2e-2), err
     # nodes without edges stay exactly zero
     deg = (g.rowptr[1:] - g.rowptr[:-1])
     assert bool((got[deg == 0] == 0).all())
