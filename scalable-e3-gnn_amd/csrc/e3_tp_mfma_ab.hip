@@ -5,8 +5,9 @@
 // l_max = 2 message products), which limits the CU to one wave per SIMD.  Measured there: ~8 cycles per issued
 // instruction, 41 % of the wave cycles inside s_waitcnt, MFMA pipe busy 14 % -- the kernel is bound by single-wave
 // issue, not by MFMA, LDS or HBM.  Here a workgroup of TWO waves owns a tile and shares its staged chunk:
-//   wave A: output degrees below the top one (for the gated products: silu scalars, the 1o gates, the 1o block)
-//   wave B: the top degree (2e) and, for gated products, the scalar tile that holds its gates
+//   wave A: output degrees below the top one (for the gated products: silu scalars, gates, the 1o block)
+//   wave B: the top degree (2e); fp32 storage: its gates arrive from wave A through LDS in the epilogue, bf16 storage:
+//           B accumulates the scalar tile with its gates itself (see RoleSplit)
 // Each wave issues half of the copies and stores its own columns, so the LDS per tile is unchanged, the registers per
 // wave halve, and 4 workgroups = 8 waves = 2 per SIMD are resident on a CU.
 //
@@ -26,15 +27,20 @@ namespace e3 {
 
 #include "e3_tp_mfma_core.h"
 
-// tiles [first, first + count) of output degree l3 that `role` (0 = A, 1 = B) accumulates
-template <int NT0, int NT1, int NT2, bool GATE>
+// tiles [first, first + count) of output degree l3 that `role` (0 = A, 1 = B) accumulates: B owns the top degree, A
+// everything below it -- including, for gated products, the scalar tile with the top block's gates, which A hands to
+// B through LDS in the epilogue (B then builds no scalar features at all; measured VALU load was 1.6x heavier on B
+// when it also carried that tile)
+// AG ("A holds the gates"): used for fp32 storage.  For bf16 storage (cheaper feature builds, other balance) it
+// measured 9 % slower than letting B accumulate its own gate tile, so there B owns scalar tile NT0-1 as well.
+template <int NT0, int NT1, int NT2, bool GATE, bool AG>
 struct RoleSplit {
   static constexpr int top = NT2 > 0 ? 2 : (NT1 > 0 ? 1 : 0);
   static constexpr int nt(int l3) { return l3 == 0 ? NT0 : l3 == 1 ? NT1 : NT2; }
-  static constexpr int first(int role, int l3) { return (role == 1 && l3 == 0 && GATE) ? NT0 - 1 : 0; }
+  static constexpr int first(int role, int l3) { return (!AG && role == 1 && l3 == 0 && GATE) ? NT0 - 1 : 0; }
   static constexpr int count(int role, int l3) {
     if (l3 == top) return role == 1 ? nt(l3) : 0;
-    if (l3 == 0 && GATE) return role == 1 ? 1 : NT0 - 1;
+    if (l3 == 0 && GATE && !AG) return role == 1 ? 1 : NT0 - 1;
     return role == 0 ? nt(l3) : 0;
   }
 };
@@ -51,7 +57,8 @@ __global__ __launch_bounds__(128, 2) void tp_fwd_mfma_ab_kernel(SegArgs segs, co
   static_assert(MODE == 1 || MODE == 2, "bf16-pipe modes only");
   constexpr bool IO16 = MODE == 2;
   constexpr int CHUNK = IO16 ? kChunk16 : kChunkFloats;
-  using RS = RoleSplit<NT0, NT1, NT2, GATE>;
+  constexpr bool AG = GATE && MODE == 1;
+  using RS = RoleSplit<NT0, NT1, NT2, GATE, AG>;
   static_assert(RS::top >= 1, "needs two output degrees");
   extern __shared__ __align__(16) unsigned char smem_raw[];
   float* lds = reinterpret_cast<float*>(smem_raw);
@@ -397,25 +404,39 @@ __global__ __launch_bounds__(128, 2) void tp_fwd_mfma_ab_kernel(SegArgs segs, co
       using I5 = std::integral_constant<int, 5>;
       if constexpr (GATE) {
         // TP out irreps = [32 scalars | 32 gates per gated block | 32x1o | 32x2e]; written layout =
-        // [silu(s) (32) | sigmoid(g1) v1 (96) | sigmoid(g2) v2 (160)].  Wave A: scalars (+ the 1o block with its
-        // gates when there are two gated blocks); wave B: the top block with its gates (its scalar tile is a0[0]).
+        // [silu(s) (32) | sigmoid(g1) v1 (96) | sigmoid(g2) v2 (160)].  Wave A holds every scalar tile: it first parks
+        // sigmoid(gates of the top block) in wave B's (still unused) LDS region, lane-for-lane in the accumulator
+        // layout, then both meet at a barrier and B picks its 16 values up.
         const float* nrm0 = nrm + ocl[cOoff[0]];
         constexpr int GT = NT0 - 1;  // scalar tile holding the gates of the top block
+        float* gx = cbuf + 32 * (NCH * DA + 4);  // = wave B's region
         if constexpr (ROLE == 0) {
+          if constexpr (AG) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gx[r * 64 + lane] = sigmoid_(a0[GT][0][r] * nrm0[32 * GT + chan_of(r)]);
+            __syncthreads();
+          }
           emit(I1{}, [&](int r, int) { const float s = a0[0][0][r] * nrm0[chan_of(r)]; return s * sigmoid_(s); },
                [&](int lc) { return lc; }, [&](int) { return -1; }, 32, true);
           if constexpr (RS::top == 2 && NT1 > 0) {
             float g[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) g[r] = sigmoid_(a0[N0 > 1 ? 1 : 0][0][r] * nrm0[32 + chan_of(r)]);
+            for (int r = 0; r < 16; ++r) g[r] = sigmoid_(a0[1][0][r] * nrm0[32 + chan_of(r)]);
             const int nb = ocl[cOoff[1]];
             emit(I3{}, [&](int r, int c) { return g[r] * a1[0][c][r]; }, [&](int lc) { return 32 + lc; },
                  [&](int lc) { return nb + lc; }, 96, true);
           }
         } else {
           float g[16];
+          if constexpr (AG) {
+            __syncthreads();
 #pragma unroll
-          for (int r = 0; r < 16; ++r) g[r] = sigmoid_(a0[0][0][r] * nrm0[32 * GT + chan_of(r)]);
+            for (int r = 0; r < 16; ++r) g[r] = gx[r * 64 + lane];
+            wave_sync_lds();  // all 16 reads done before this wave overwrites the region
+          } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) g[r] = sigmoid_(a0[0][0][r] * nrm0[32 * GT + chan_of(r)]);
+          }
           const int nb = ocl[cOoff[RS::top]];
           const int ocol = 32 + (RS::top == 2 && NT1 > 0 ? 96 : 0);
           if constexpr (RS::top == 2)
