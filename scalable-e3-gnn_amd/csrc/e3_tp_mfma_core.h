@@ -507,14 +507,14 @@ __device__ __forceinline__ void run_steps_bf_lean(const float* __restrict__ xr, 
       }
       const bf16x8 bh = __builtin_bit_cast(bf16x8, uint4{ph[0], ph[1], ph[2], ph[3]});
       const bf16x8 bl = __builtin_bit_cast(bf16x8, uint4{pl[0], pl[1], pl[2], pl[3]});
+      // product-major order: consecutive MFMAs write different accumulators (the three products of one tile are a
+      // dependent chain)
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const bf16x8 wh = __builtin_bit_cast(bf16x8, ah[t]);
-        const bf16x8 wl = __builtin_bit_cast(bf16x8, al[t]);
-        acc[t][c] = mfma_bf16(wh, bh, acc[t][c]);
-        acc[t][c] = mfma_bf16(wh, bl, acc[t][c]);
-        acc[t][c] = mfma_bf16(wl, bh, acc[t][c]);
-      }
+      for (int t = 0; t < NT; ++t) acc[t][c] = mfma_bf16(__builtin_bit_cast(bf16x8, ah[t]), bh, acc[t][c]);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t][c] = mfma_bf16(__builtin_bit_cast(bf16x8, ah[t]), bl, acc[t][c]);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t][c] = mfma_bf16(__builtin_bit_cast(bf16x8, al[t]), bh, acc[t][c]);
     }
     if (kb + 1 < nkb) {
 #pragma unroll
