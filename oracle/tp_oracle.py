@@ -82,7 +82,7 @@ def forward(in1_irreps, out_irreps, lmax_sh, in1, in2, W, norms):
             continue
         F = np.concatenate(feats, 1)                              # [B, K, 2l3+1]
         o = np.einsum("bkq,kw->bwq", F, np.asarray(W[name], np.float64), optimize=True)
-        o = o.reshape(B, -1) * np.asarray(norms[name], np.float64)
+        o = o.reshape(B, o.shape[1] * o.shape[2]) * np.asarray(norms[name], np.float64)  # explicit width: B may be 0
         out[:, oc[c3].reshape(-1)] = o
     return out
 
