@@ -68,7 +68,7 @@ class SlabHalo:
         cnt_l, cnt_r = torch.zeros(1, dtype=torch.int64, device=dev), torch.zeros(1, dtype=torch.int64, device=dev)
         self._sendrecv(cnt_out[0:1].contiguous(), cnt_out[1:2].contiguous(), cnt_l, cnt_r)
         self.n_ghost_left, self.n_ghost_right = int(cnt_l.item()), int(cnt_r.item())
-        payload = torch.cat([pos, feats], 1)
+        payload = torch.cat([pos, feats.to(pos.dtype)], 1)  # one message; bf16 features ride as fp32 (lossless)
         F = payload.shape[1]
         gl = torch.empty((self.n_ghost_left, F), dtype=payload.dtype, device=dev)
         gr = torch.empty((self.n_ghost_right, F), dtype=payload.dtype, device=dev)
@@ -78,7 +78,7 @@ class SlabHalo:
         self._send_right_idx = self.sel_right
         self._recv_left_idx = torch.arange(n, n + self.n_ghost_left, device=dev)
         self._recv_right_idx = torch.arange(n + self.n_ghost_left, n + self.n_ghost_left + self.n_ghost_right, device=dev)
-        return local[:, :3].contiguous(), local[:, 3:].contiguous()
+        return local[:, :3].contiguous(), local[:, 3:].to(feats.dtype).contiguous()
 
     def renumber(self, perm: torch.Tensor):
         """The graph builder renumbers the local cloud (``perm[new] = old``): translate the halo index lists."""

@@ -46,6 +46,12 @@ def _worker(rank, world, port, N, H, L, out_q):
         own = ((pos[:, 0] >= rank) & (pos[:, 0] < rank + 1)).nonzero().flatten()
         halo = SlabHalo()
         lpos, lx = halo.setup(pos[own].float().double(), x[own], float(rank), float(rank + 1), r)
+        # features of another storage type than the positions keep their dtype through the exchange (bf16 storage
+        # with fp32 positions is what `bench.py --gpus N` sends for its bf16 leg)
+        h2 = SlabHalo()
+        p32, f16 = h2.setup(pos[own].float(), x[own].to(torch.bfloat16), float(rank), float(rank + 1), r)
+        assert p32.dtype == torch.float32 and f16.dtype == torch.bfloat16 and f16.shape[0] == p32.shape[0]
+        assert torch.equal(f16[: own.numel()], x[own].to(torch.bfloat16))
         lo, hi = [rank - 2 * r, 0, 0], [rank + 1 + 2 * r, 1, 1]
         perm, rowptr, src = G.graph(lpos.numpy(), lo, hi, r)
         halo.renumber(torch.as_tensor(perm))
