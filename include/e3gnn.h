@@ -225,6 +225,15 @@ int e3_tp_forward(const e3_tp_plan* plan, const void* in1, int64_t ld_in1, const
 int e3_tp_forward_fused(const e3_tp_plan* plan, const e3_tp_segment* segs, int nseg,
                         const void* in2, int64_t ld_in2, const void* packed, void* out, int64_t ld_out,
                         int64_t B, int dtype, int gate, void* stream);
+/* Gradients of e3_tp_forward (fp32 / fp64; the reference operator relies on torch autograd, l1_tensor_prod.py:240-299).
+ * `packed` = the buffer e3_tp_pack_weights wrote for this dtype.  Any of grad_in1 [B, in1_dim] (storage dtype),
+ * grad_in2 [B, in2_dim] (ACCUMULATION dtype: fp32 for E3_F32, fp64 for E3_F64; with broadcast in2, ld_in2 == 0, pass
+ * ld_gin2 == 0 and a zero-filled [in2_dim] row) and grad_weights[6] (one [rows, cols] array per output class as
+ * e3_tp_weight_shape reports, accumulation dtype, ZERO-FILLED by the caller, nullptr to skip a class) may be null.
+ * grad_weights (and the broadcast grad_in2) are accumulated with atomics: sums are not bitwise reproducible. */
+int e3_tp_backward(const e3_tp_plan* plan, const void* in1, int64_t ld_in1, const void* in2, int64_t ld_in2,
+                   const void* packed, const void* grad_out, int64_t ld_gout, void* grad_in1, int64_t ld_gin1,
+                   void* grad_in2, int64_t ld_gin2, void* const grad_weights[6], int64_t B, int dtype, void* stream);
 int e3_tp_fused_supported(const e3_tp_plan* plan, int gate);
 /* e3_tp_forward_fused with the message pass's segment-sum fused into the epilogue: row b of the (gated) product is not
  * stored but ADDED to out_nodes[row_node[b]] (fp32 atomics; row_node ascending, e.g. the dst column of a CSR-by-dst

@@ -61,6 +61,8 @@ SIGNATURES = {
                               c_int, c_void_p]),
     "e3_tp_forward_fused": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64,
                                     c_int, c_int, c_void_p]),
+    "e3_tp_backward": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
+                               c_int64, c_void_p, c_int64, c_void_p * 6, c_int64, c_int, c_void_p]),
     "e3_tp_fused_supported": (c_int, [c_void_p, c_int]),
     "e3_tp_forward_fused_scatter": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
                                             c_int64, c_int64, c_int, c_int, c_void_p]),

@@ -5,8 +5,9 @@ A batch of molecules is ONE radius graph: the molecules are laid out on a 3-D la
 molecule by two cutoff radii, so the cell-list builder (`e3_rg_*`) finds exactly the intra-molecular pairs in one pass,
 with the same kernels as the single-cloud path.  The neighbour search runs on the lattice copy; the graph that is
 returned carries the ORIGINAL coordinates, so edge vectors / spherical harmonics see no shift rounding.  The energy
-head is the per-molecule sum of a scalar (`1x0e`) node readout.  Forces (-dE/dpos) need the backward of the general
-tensor product, which does not exist yet: requesting them raises.
+head is the per-molecule sum of a scalar (`1x0e`) node readout.  Forces (-dE/dpos) need gradients through the whole
+message pass: the tensor product has its backward (`e3_tp_backward`), the edge-geometry / gather / gate / segment-sum
+kernels do not yet: requesting forces raises.
 """
 from __future__ import annotations
 
@@ -59,7 +60,8 @@ class BatchedEnergyModel(nn.Module):
 
     def forward(self, x: torch.Tensor, pos: torch.Tensor, batch: torch.Tensor, r: float, forces: bool = False):
         if forces:
-            raise NotImplementedError("forces need the backward of the general tensor product (DESIGN.md §8)")
+            raise NotImplementedError("forces need backward kernels for edge geometry / gather / gate / segment-sum "
+                                      "(the tensor product has one): DESIGN.md §8")
         g, mol = batched_radius_graph(pos, batch, r)
         e_node = self.net(x[g.perm.long()], g)
         n_mol = int(batch.max().item()) + 1 if batch.numel() else 0

@@ -175,6 +175,264 @@ static int tp_launch_fwd(const e3_tp_plan* plan, const void* in1, int64_t ld1, c
   return E3_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// backward of the general tensor product (generic FMA kernels, fp32 / fp64; the reference's operator gets its
+// gradients from torch autograd over l1_tensor_prod.py:240-299 -- these kernels are that for l <= 2)
+//   out[b, w, c] = norm[w,c] * sum_paths sum_k W[k, w] * sum_{a,bq} C[a][bq][c] x[b,k,a] y[b,bq]
+// ---------------------------------------------------------------------------------------------------
+template <int L1, int L2, int L3, typename A>
+struct TpGrad {
+  static constexpr bool ok = CG<L1, L2, L3>::valid;
+  static constexpr int D1 = 2 * L1 + 1, D2 = 2 * L2 + 1, D3 = 2 * L3 + 1;
+  // gx[a] += wv * sum_{bq,c} C y[bq] g[c]
+  static __device__ __forceinline__ void gx(A wv, const A* y, const A* g, A* gxa) {
+    if constexpr (ok) {
+#pragma unroll
+      for (int a = 0; a < D1; ++a) {
+        A s = 0;
+#pragma unroll
+        for (int bq = 0; bq < D2; ++bq)
+#pragma unroll
+          for (int c = 0; c < D3; ++c)
+            if (CG<L1, L2, L3>::v[a][bq][c] != 0.0) s += A(CG<L1, L2, L3>::v[a][bq][c]) * y[bq] * g[c];
+        gxa[a] += wv * s;
+      }
+    }
+  }
+  // gy[bq] += wv * sum_{a,c} C x[a] g[c]
+  static __device__ __forceinline__ void gy(A wv, const A* x, const A* g, A* gyb) {
+    if constexpr (ok) {
+#pragma unroll
+      for (int bq = 0; bq < D2; ++bq) {
+        A s = 0;
+#pragma unroll
+        for (int a = 0; a < D1; ++a)
+#pragma unroll
+          for (int c = 0; c < D3; ++c)
+            if (CG<L1, L2, L3>::v[a][bq][c] != 0.0) s += A(CG<L1, L2, L3>::v[a][bq][c]) * x[a] * g[c];
+        gyb[bq] += wv * s;
+      }
+    }
+  }
+  // sum_{a,bq,c} C x[a] y[bq] g[c]
+  static __device__ __forceinline__ A gw(const A* x, const A* y, const A* g) {
+    A s = 0;
+    if constexpr (ok) {
+#pragma unroll
+      for (int a = 0; a < D1; ++a)
+#pragma unroll
+        for (int bq = 0; bq < D2; ++bq)
+#pragma unroll
+          for (int c = 0; c < D3; ++c)
+            if (CG<L1, L2, L3>::v[a][bq][c] != 0.0) s += A(CG<L1, L2, L3>::v[a][bq][c]) * x[a] * y[bq] * g[c];
+    }
+    return s;
+  }
+};
+#define E3_GRAD_SWITCH(l1, l2, l3, CALL)                                                                     \
+  switch ((l1) * 9 + (l2) * 3 + (l3)) {                                                                      \
+    case 0: { using G = TpGrad<0, 0, 0, A>; CALL; } break;   case 4: { using G = TpGrad<0, 1, 1, A>; CALL; } break;  \
+    case 8: { using G = TpGrad<0, 2, 2, A>; CALL; } break;   case 10: { using G = TpGrad<1, 0, 1, A>; CALL; } break; \
+    case 12: { using G = TpGrad<1, 1, 0, A>; CALL; } break;  case 13: { using G = TpGrad<1, 1, 1, A>; CALL; } break; \
+    case 14: { using G = TpGrad<1, 1, 2, A>; CALL; } break;  case 16: { using G = TpGrad<1, 2, 1, A>; CALL; } break; \
+    case 17: { using G = TpGrad<1, 2, 2, A>; CALL; } break;  case 20: { using G = TpGrad<2, 0, 2, A>; CALL; } break; \
+    case 22: { using G = TpGrad<2, 1, 1, A>; CALL; } break;  case 23: { using G = TpGrad<2, 1, 2, A>; CALL; } break; \
+    case 24: { using G = TpGrad<2, 2, 0, A>; CALL; } break;  case 25: { using G = TpGrad<2, 2, 1, A>; CALL; } break; \
+    case 26: { using G = TpGrad<2, 2, 2, A>; CALL; } break;  default: break;                                    \
+  }
+
+// stage R rows: x in class order, y, g' = grad_out * norm (original out column order)
+template <typename T, typename A>
+__device__ __forceinline__ void tp_bwd_stage(const T* in1, int64_t ld1, const T* in2, int64_t ld2, const T* go, int64_t ldg,
+                                             const A* normcol, int64_t row0, int R, int64_t B, const TpDev& p, A* xs,
+                                             A* ys, A* gs) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int i = tid; i < R * p.D1; i += nt) {
+    int r = i / p.D1, d = i - r * p.D1;
+    int64_t row = row0 + r;
+    xs[r * p.D1 + p.cpos[d]] = row < B ? to_acc(in1[row * ld1 + d]) : A(0);
+  }
+  for (int i = tid; i < R * p.Dy; i += nt) {
+    int r = i / p.Dy, d = i - r * p.Dy;
+    int64_t row = row0 + r;
+    ys[i] = row < B ? to_acc(in2[row * ld2 + d]) : A(0);
+  }
+  for (int i = tid; i < R * p.Dout; i += nt) {
+    int r = i / p.Dout, d = i - r * p.Dout;
+    int64_t row = row0 + r;
+    gs[i] = row < B ? to_acc(go[row * ldg + d]) * normcol[d] : A(0);
+  }
+}
+
+template <typename T, int R>
+__global__ __launch_bounds__(256) void tp_bwd_rows_kernel(const T* __restrict__ in1, int64_t ld1, const T* __restrict__ in2,
+                                                          int64_t ld2, const typename AccOf<T>::type* __restrict__ packed,
+                                                          const T* __restrict__ go, int64_t ldg, T* __restrict__ gin1,
+                                                          int64_t ldg1, typename AccOf<T>::type* __restrict__ gin2,
+                                                          int64_t ldg2, int64_t B, TpDev p) {
+  using A = typename AccOf<T>::type;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  A* xs = reinterpret_cast<A*>(smem_raw);
+  A* ys = xs + (size_t)R * p.D1;
+  A* gs = ys + (size_t)R * p.Dy;
+  A* gx = gs + (size_t)R * p.Dout;
+  A* gy = gx + (size_t)R * p.D1;
+  const int tid = threadIdx.x;
+  int Ktot = 0, Mtot = 0;
+  for (int c = 0; c < 6; ++c) { Ktot += p.n[c]; Mtot += p.M[c]; }
+  const A* normcol = packed + p.normcol_off;
+  const int64_t ntiles = (B + R - 1) / R;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t row0 = tile * R;
+    tp_bwd_stage<T, A>(in1, ld1, in2, ld2, go, ldg, normcol, row0, R, B, p, xs, ys, gs);
+    for (int i = tid; i < R * 9; i += 256) gy[i] = 0;
+    __syncthreads();
+    if (gin1) {  // thread = (row, in channel): sum over every path that reads this channel and every out channel
+      for (int i = tid; i < R * Ktot; i += 256) {
+        int r = i / Ktot, kk = i - r * Ktot, c1 = 0;
+        while (kk >= p.n[c1]) { kk -= p.n[c1]; ++c1; }
+        const int l1 = c1 >> 1, D1c = 2 * l1 + 1;
+        A acc[5] = {0, 0, 0, 0, 0};
+        const A* y = ys + r * p.Dy;
+        for (int c3 = 0; c3 < 6; ++c3) {
+          const int l3 = c3 >> 1, M = p.M[c3];
+          for (int pi = 0; pi < p.npath[c3]; ++pi) {
+            const TpPath P = p.paths[p.poff[c3] + pi];
+            if (P.c1 != c1) continue;
+            const A* W = packed + p.woff[c3] + (int64_t)(P.wrow + kk) * M;
+            const A* yl = y + P.l2 * P.l2;
+            for (int w = 0; w < M; ++w) {
+              const A* g = gs + r * p.Dout + p.ocol[p.ocol_off[c3] + w];
+              const A wv = W[w];
+              E3_GRAD_SWITCH(l1, P.l2, l3, G::gx(wv, yl, g, acc))
+            }
+          }
+        }
+        for (int a = 0; a < D1c; ++a) gx[r * p.D1 + p.cbase[c1] + kk * D1c + a] = acc[a];
+      }
+    }
+    if (gin2) {  // thread = (row, out channel): partial sums over the in channels, reduced through LDS atomics
+      for (int i = tid; i < R * Mtot; i += 256) {
+        int r = i / Mtot, w = i - r * Mtot, c3 = 0;
+        while (w >= p.M[c3]) { w -= p.M[c3]; ++c3; }
+        const int l3 = c3 >> 1, M = p.M[c3];
+        const A* g = gs + r * p.Dout + p.ocol[p.ocol_off[c3] + w];
+        A loc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int pi = 0; pi < p.npath[c3]; ++pi) {
+          const TpPath P = p.paths[p.poff[c3] + pi];
+          const int D1c = 2 * P.l1 + 1;
+          const A* xc = xs + r * p.D1 + p.cbase[P.c1];
+          const A* W = packed + p.woff[c3] + (int64_t)P.wrow * M + w;
+          for (int k = 0; k < p.n[P.c1]; ++k) {
+            const A wv = W[(int64_t)k * M];
+            E3_GRAD_SWITCH(P.l1, P.l2, l3, G::gy(wv, xc + k * D1c, g, loc + P.l2 * P.l2))
+          }
+        }
+        for (int q = 0; q < p.Dy; ++q) atomicAdd(&gy[r * 9 + q], loc[q]);
+      }
+    }
+    __syncthreads();
+    if (gin1)
+      for (int i = tid; i < R * p.D1; i += 256) {
+        int r = i / p.D1, d = i - r * p.D1;
+        if (row0 + r < B) gin1[(row0 + r) * ldg1 + d] = from_acc<T, A>(gx[r * p.D1 + p.cpos[d]]);
+      }
+    if (gin2)
+      for (int i = tid; i < R * p.Dy; i += 256) {
+        int r = i / p.Dy, q = i - r * p.Dy;
+        if (row0 + r < B) {
+          if (ldg2 == 0) atomicAdd(&gin2[q], gy[r * 9 + q]);   // broadcast in2: one row of sums (caller zero-fills)
+          else gin2[(row0 + r) * ldg2 + q] = gy[r * 9 + q];
+        }
+      }
+    __syncthreads();
+  }
+}
+
+// grad_W[c3][krow][w] += sum_b sum C x y g'   (atomics into zero-filled fp32 / fp64 arrays, one per out class)
+template <typename T, int R>
+__global__ __launch_bounds__(256) void tp_bwd_w_kernel(const T* __restrict__ in1, int64_t ld1, const T* __restrict__ in2,
+                                                       int64_t ld2, const typename AccOf<T>::type* __restrict__ packed,
+                                                       const T* __restrict__ go, int64_t ldg,
+                                                       typename AccOf<T>::type* g0, typename AccOf<T>::type* g1,
+                                                       typename AccOf<T>::type* g2, typename AccOf<T>::type* g3,
+                                                       typename AccOf<T>::type* g4, typename AccOf<T>::type* g5,
+                                                       int64_t B, TpDev p) {
+  using A = typename AccOf<T>::type;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  A* xs = reinterpret_cast<A*>(smem_raw);
+  A* ys = xs + (size_t)R * p.D1;
+  A* gs = ys + (size_t)R * p.Dy;
+  A* gw[6] = {g0, g1, g2, g3, g4, g5};
+  const int tid = threadIdx.x;
+  const A* normcol = packed + p.normcol_off;
+  int64_t Wtot = 0;
+  for (int c = 0; c < 6; ++c) Wtot += (int64_t)p.K[c] * p.M[c];
+  const int64_t ntiles = (B + R - 1) / R;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t row0 = tile * R;
+    __syncthreads();
+    tp_bwd_stage<T, A>(in1, ld1, in2, ld2, go, ldg, normcol, row0, R, B, p, xs, ys, gs);
+    __syncthreads();
+    for (int64_t i = tid; i < Wtot; i += 256) {
+      int64_t e = i;
+      int c3 = 0;
+      while (e >= (int64_t)p.K[c3] * p.M[c3]) { e -= (int64_t)p.K[c3] * p.M[c3]; ++c3; }
+      if (!gw[c3]) continue;
+      const int M = p.M[c3], krow = (int)(e / M), w = (int)(e - (int64_t)krow * M), l3 = c3 >> 1;
+      TpPath P = p.paths[p.poff[c3]];
+      for (int pi = 0; pi < p.npath[c3]; ++pi) {
+        const TpPath Q = p.paths[p.poff[c3] + pi];
+        if (krow >= Q.wrow) P = Q;
+      }
+      const int kk = krow - P.wrow, D1c = 2 * P.l1 + 1;
+      const int oc = p.ocol[p.ocol_off[c3] + w];
+      A acc = 0;
+      for (int r = 0; r < R; ++r) {
+        const A* x = xs + r * p.D1 + p.cbase[P.c1] + kk * D1c;
+        const A* y = ys + r * p.Dy + P.l2 * P.l2;
+        const A* g = gs + r * p.Dout + oc;
+        E3_GRAD_SWITCH(P.l1, P.l2, l3, acc += G::gw(x, y, g))
+      }
+      atomicAdd(&gw[c3][e], acc);
+    }
+  }
+}
+
+template <typename T>
+static int tp_launch_bwd(const e3_tp_plan* plan, const void* in1, int64_t ld1, const void* in2, int64_t ld2,
+                         const void* packed, const void* go, int64_t ldg, void* gin1, int64_t ldg1, void* gin2,
+                         int64_t ldg2, void* const gw[6], int64_t B, hipStream_t s) {
+  using A = typename AccOf<T>::type;
+  const TpDev& p = plan->dev;
+  constexpr int R = 4;
+  if (gin1 || gin2) {
+    const size_t lds = (size_t)R * (2 * p.D1 + p.Dy + p.Dout + 9) * sizeof(A);
+    if (lds > 160 * 1024) return E3_ERR_UNSUPPORTED;
+    auto k = tp_bwd_rows_kernel<T, R>;
+    E3_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int grid = (int)std::min<int64_t>((B + R - 1) / R, 256 * 4);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, (const T*)in1, ld1, (const T*)in2, ld2, (const A*)packed,
+                       (const T*)go, ldg, (T*)gin1, ldg1, (A*)gin2, ldg2, B, p);
+    E3_HIP_CHECK(hipGetLastError());
+  }
+  bool anyw = false;
+  for (int c = 0; c < 6; ++c) anyw |= gw[c] != nullptr;
+  if (anyw) {
+    constexpr int RW = 8;
+    const size_t lds = (size_t)RW * (p.D1 + p.Dy + p.Dout) * sizeof(A);
+    if (lds > 160 * 1024) return E3_ERR_UNSUPPORTED;
+    auto k = tp_bwd_w_kernel<T, RW>;
+    E3_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int grid = (int)std::min<int64_t>((B + RW - 1) / RW, 256 * 2);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, (const T*)in1, ld1, (const T*)in2, ld2, (const A*)packed,
+                       (const T*)go, ldg, (A*)gw[0], (A*)gw[1], (A*)gw[2], (A*)gw[3], (A*)gw[4], (A*)gw[5], B, p);
+    E3_HIP_CHECK(hipGetLastError());
+  }
+  return E3_OK;
+}
+
 }  // namespace e3
 
 using namespace e3;
@@ -386,6 +644,26 @@ int e3_tp_forward_fused_scatter(const e3_tp_plan* plan, const e3_tp_segment* seg
   if (st != E3_OK) return st;
   return fast_forward(&plan->fast, segs, nseg, plan->dev.D1, in2, ld2, (const char*)packed + fast_section_offset(plan),
                       out_nodes, ldo, B, gate, dtype, plan->dev.ocol, (hipStream_t)stream, row_node);
+}
+
+int e3_tp_backward(const e3_tp_plan* plan, const void* in1, int64_t ld1, const void* in2, int64_t ld2,
+                   const void* packed, const void* grad_out, int64_t ldg, void* grad_in1, int64_t ldg1,
+                   void* grad_in2, int64_t ldg2, void* const grad_weights[6], int64_t B, int dtype, void* stream) {
+  if (!plan || B < 0 || (dtype != E3_F32 && dtype != E3_F64)) return E3_ERR_INVALID_ARG;
+  if (B == 0) return E3_OK;
+  if (!in1 || !in2 || !packed || !grad_out) return E3_ERR_INVALID_ARG;
+  if (ld1 < plan->dev.D1 || ldg < plan->dev.Dout || (ld2 != 0 && ld2 < plan->dev.Dy)) return E3_ERR_INVALID_ARG;
+  if (grad_in1 && ldg1 < plan->dev.D1) return E3_ERR_INVALID_ARG;
+  if (grad_in2 && ((ld2 == 0) != (ldg2 == 0) || (ldg2 != 0 && ldg2 < plan->dev.Dy))) return E3_ERR_INVALID_ARG;
+  int st = tp_ensure_device(plan);
+  if (st != E3_OK) return st;
+  void* none[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  void* const* gw = grad_weights ? grad_weights : none;
+  hipStream_t s = (hipStream_t)stream;
+  return dtype == E3_F32 ? tp_launch_bwd<float>(plan, in1, ld1, in2, ld2, packed, grad_out, ldg, grad_in1, ldg1, grad_in2,
+                                                ldg2, gw, B, s)
+                         : tp_launch_bwd<double>(plan, in1, ld1, in2, ld2, packed, grad_out, ldg, grad_in1, ldg1,
+                                                 grad_in2, ldg2, gw, B, s);
 }
 
 // diagnostic: per-phase wave-cycle sums of the MFMA kernel (E3_TP_DBG & 8); reads and clears

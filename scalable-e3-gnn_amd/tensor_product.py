@@ -168,6 +168,60 @@ class TPPlan:
         return out
 
 
+class _SHTPFunction(torch.autograd.Function):
+    """autograd bridge: forward = e3_tp_forward, backward = e3_tp_backward (fp32 / fp64)."""
+
+    @staticmethod
+    def forward(ctx, mod, in1, in2, *weights):
+        out = mod._forward_impl(in1, in2)
+        ctx.mod = mod
+        ctx.save_for_backward(in1, in2, *weights)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        mod = ctx.mod
+        in1, in2, *weights = ctx.saved_tensors
+        lib = _lib.load()
+        B = in1.shape[0]
+        if grad_out.stride(-1) != 1 or grad_out.dtype != in1.dtype:
+            grad_out = grad_out.to(in1.dtype).contiguous()
+        acc = torch.float64 if in1.dtype == torch.float64 else torch.float32
+        need1, need2 = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        bcast = in2.shape[0] == 1 and B != 1
+        g1 = torch.empty_like(in1) if need1 else None
+        g2 = (torch.zeros((1, mod.in2_dim), dtype=acc, device=in1.device) if bcast else
+              torch.empty((B, mod.in2_dim), dtype=acc, device=in1.device)) if need2 else None
+        present = [c for c in CLASSES if hasattr(mod, "weights_" + c)]
+        gws, ptrs, wi = [], [], 0
+        for c in CLASSES:
+            if c in present:
+                need = ctx.needs_input_grad[3 + wi]
+                gw = torch.zeros(weights[wi].shape, dtype=acc, device=in1.device) if need else None
+                gws.append(gw)
+                ptrs.append(gw.data_ptr() if gw is not None else None)
+                wi += 1
+            else:
+                ptrs.append(None)
+        if B > 0:
+            with torch.cuda.device(in1.device):
+                packed = mod._packed_weights(in1.dtype, in1.device)
+                stream = torch.cuda.current_stream(in1.device).cuda_stream
+                _lib.check(lib.e3_tp_backward(mod._handle, in1.data_ptr(), in1.stride(0), in2.data_ptr(),
+                                              0 if bcast else in2.stride(0), packed.data_ptr(), grad_out.data_ptr(),
+                                              grad_out.stride(0), g1.data_ptr() if g1 is not None else None,
+                                              in1.stride(0) if g1 is not None else 0,
+                                              g2.data_ptr() if g2 is not None else None,
+                                              0 if (g2 is None or bcast) else g2.stride(0),
+                                              (ctypes.c_void_p * 6)(*ptrs), B, _lib.dtype_code(in1.dtype), stream),
+                           "e3_tp_backward")
+        elif g1 is not None or g2 is not None:
+            g2 = torch.zeros_like(g2) if g2 is not None else None
+        out = [None, g1, g2.to(in2.dtype) if g2 is not None else None]
+        out += [gw.to(w.dtype) if gw is not None else None for gw, w in zip(gws, weights)]
+        return tuple(out)
+
+
 class SHTensorProduct(nn.Module):
     def __init__(self, in1_irreps, out_irreps, lmax_sh: int = 2):
         super().__init__()
@@ -215,7 +269,17 @@ class SHTensorProduct(nn.Module):
             raise RuntimeError("SHTensorProduct runs on ROCm tensors only; there is no CPU path")
         if torch.is_grad_enabled() and (in1.requires_grad or in2.requires_grad or
                                         any(p.requires_grad for p in self.parameters())):
-            raise NotImplementedError("SHTensorProduct is forward-only for now: call it under torch.no_grad()")
+            if in1.dtype not in (torch.float32, torch.float64):
+                raise NotImplementedError("SHTensorProduct backward: float32 / float64 only")
+            if in1.stride(-1) != 1:
+                in1 = in1.contiguous()
+            if in2.stride(-1) != 1:
+                in2 = in2.contiguous()
+            ws = [getattr(self, "weights_" + c) for c in CLASSES if hasattr(self, "weights_" + c)]
+            return _SHTPFunction.apply(self, in1, in2, *ws)
+        return self._forward_impl(in1, in2)
+
+    def _forward_impl(self, in1: torch.Tensor, in2: torch.Tensor) -> torch.Tensor:
         B = in1.shape[0]
         out = torch.empty((B, self.out_dim), dtype=in1.dtype, device=in1.device)
         if B == 0:
