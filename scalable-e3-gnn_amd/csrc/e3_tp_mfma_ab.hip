@@ -33,6 +33,8 @@ namespace e3 {
 // when it also carried that tile)
 // AG ("A holds the gates"): used for fp32 storage.  For bf16 storage (cheaper feature builds, other balance) it
 // measured 9 % slower than letting B accumulate its own gate tile, so there B owns scalar tile NT0-1 as well.
+constexpr int kChunkAb16 = 32 * (16 * 3 + 4) + 32 * (16 * 5 + 4);  // 4352 dwords >= kChunk16
+
 template <int NT0, int NT1, int NT2, bool GATE, bool AG>
 struct RoleSplit {
   static constexpr int top = NT2 > 0 ? 2 : (NT1 > 0 ? 1 : 0);
@@ -56,7 +58,9 @@ __global__ __launch_bounds__(128, 2) void tp_fwd_mfma_ab_kernel(SegArgs segs, co
                                                                  const int32_t* __restrict__ ocol_tab) {
   static_assert(MODE == 1 || MODE == 2, "bf16-pipe modes only");
   constexpr bool IO16 = MODE == 2;
-  constexpr int CHUNK = IO16 ? kChunk16 : kChunkFloats;
+  // the chunk buffer doubles as the epilogue's transposition space: two passes of 16 channels for both waves need 4352
+  // dwords, more than a bf16 chunk (2688) -- the buffer is sized for the larger of the two
+  constexpr int CHUNK = IO16 ? kChunkAb16 : kChunkFloats;
   constexpr bool AG = GATE && MODE == 1;
   using RS = RoleSplit<NT0, NT1, NT2, GATE, AG>;
   static_assert(RS::top >= 1, "needs two output degrees");
@@ -301,7 +305,7 @@ __global__ __launch_bounds__(128, 2) void tp_fwd_mfma_ab_kernel(SegArgs segs, co
 
       // ---- epilogue: each wave transposes its own tiles through its own region of the (now dead) chunk buffer ----
       wait_vm0();
-      constexpr int NPASS = IO16 ? 4 : 2, NCH = 32 / NPASS, RPP = 16 / NPASS;
+      constexpr int NPASS = 2, NCH = 32 / NPASS, RPP = 16 / NPASS;
       constexpr int DA = NT1 > 0 && RS::top > 1 ? 3 : 1;  // widest tile of role A
       static_assert(32 * (NCH * DA + 4) + 32 * (NCH * (2 * RS::top + 1) + 4) <= CHUNK, "epilogue regions");
       float* ot = cbuf + (ROLE == 1 ? 32 * (NCH * DA + 4) : 0);
@@ -488,7 +492,7 @@ struct AbKernelEntry {
     {(const void*)tp_fwd_mfma_ab_kernel<LSH, a, b, c, false, 2, false, __VA_ARGS__>,                           \
      (const void*)tp_fwd_mfma_ab_kernel<LSH, a, b, c, true, 2, false, __VA_ARGS__>}},                          \
    {SC ? (const void*)tp_fwd_mfma_ab_kernel<LSH, a, b, c, true, 1, SC, __VA_ARGS__> : nullptr,                 \
-    nullptr /* bf16 storage: measured slower than the two kernels (4 narrow passes per tile), not instantiated */}}
+    nullptr /* bf16 storage: measured 2 % slower than the two kernels (the bf16 segment-sum only reads 13.5 GB) */}}
 static const std::vector<AbKernelEntry>& ab_kernels() {
   static const std::vector<AbKernelEntry> k = {
       E3_AB(2, 3, 1, 1, false, 0, 1, 2, 0, 1, 2, 0),  // message TP #1
@@ -520,7 +524,7 @@ int fast_forward_ab(const TpFast* F, const void* sa_, const void* in2, int64_t l
   if (scat && (!gate || !e->fn_scat[mode - 1])) return 0;
   const void* fn = scat ? e->fn_scat[mode - 1] : e->fn[mode - 1][gate ? 1 : 0];
   const size_t lds_bytes = (size_t)(((d.Dout + 4 + 15) & ~15) + ((d.ntab + 15) & ~15) +
-                                    (mode == 2 ? kChunk16 : kChunkFloats) + 320) * 4;
+                                    (mode == 2 ? kChunkAb16 : kChunkFloats) + 320) * 4;
   static std::vector<const void*> configured;
   if (std::find(configured.begin(), configured.end(), fn) == configured.end()) {
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return -E3_ERR_HIP;
