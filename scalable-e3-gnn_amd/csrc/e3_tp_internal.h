@@ -61,4 +61,8 @@ int fast_forward(const TpFast* F, const e3_tp_segment* segs, int nseg, int D1, c
 int fast_forward_ab(const TpFast* F, const void* seg_args, const void* in2, int64_t ld2, const void* packed, void* out,
                     int64_t ldo, int64_t B, int gate, int mode, const int32_t* ocol_tab, hipStream_t s);
 
+// 16-row kernel (e3_tp_mfma_r16.hip): same contract as fast_forward_ab
+int fast_forward_r16(const TpFast* F, const void* seg_args, const void* in2, int64_t ld2, const void* packed, void* out,
+                     int64_t ldo, int64_t B, int gate, int mode, const int32_t* ocol_tab, hipStream_t s);
+
 }  // namespace e3

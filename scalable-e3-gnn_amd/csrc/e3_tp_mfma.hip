@@ -281,7 +281,8 @@ int fast_forward(const TpFast* F, const e3_tp_segment* segs, int nseg, int D1, c
       return E3_ERR_UNSUPPORTED;
   }
   {
-    const int r = fast_forward_ab(F, &sa, in2, ld2, packed, out, ldo, B, gate, mode, ocol_tab, s);
+    int r = fast_forward_r16(F, &sa, in2, ld2, packed, out, ldo, B, gate, mode, ocol_tab, s);
+    if (r == 0) r = fast_forward_ab(F, &sa, in2, ld2, packed, out, ldo, B, gate, mode, ocol_tab, s);
     if (r == 1) return E3_OK;
     if (r < 0) return -r;
     if (scatter) return E3_ERR_UNSUPPORTED;  // only the two-wave kernel has the fused segment-sum
