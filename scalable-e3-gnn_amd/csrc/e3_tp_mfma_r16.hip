@@ -11,7 +11,7 @@
 // k group (the same 2*D1 ds_read_b128 as the 32-row kernel's half).  A operand: W[k = 8g + i][channel = lane & 15] -- the
 // packed [16-row block][k half][channel][8] layout already serves it: uint4 index (2 * wblk + g) * Mpad + channel.
 // Accumulator: channels 4g + r (r < 4) of the lane's row.  Operand mode: fp32 storage with bf16x3-split operands (MODE 1)
-// or bf16 storage (MODE 2), as in the other kernels.  E3_TP_R16=0 disables it.
+// or bf16 storage (MODE 2), as in the other kernels.  Default for fp32 storage (see r16_level).
 #include "e3_common.h"
 #include "cg_tables.h"
 #include "e3_tp_internal.h"
@@ -33,11 +33,38 @@ __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
 constexpr int kChunkR16 = 16 * 41 * 4;     // fp32 storage: 16 rows x 41 16-byte units (= 16 x 164 dwords: also the out tile)
 constexpr int kChunkR16h = 16 * (32 * 5 + 4);  // bf16 storage: sized by the out tile (16 rows x 164 dwords)
 
+// this lane's operand slice of a staged chunk: 8 channels (k group g) x D1 components, read ONCE per chunk and shared
+// by every path of the chunk
+template <int L1, bool IO16>
+__device__ __forceinline__ void load_x16(const float* __restrict__ xr, const int g, float (&x)[8][2 * L1 + 1]) {
+  constexpr int D1 = 2 * L1 + 1;
+  if constexpr (IO16) {
+    const uint4* xv = reinterpret_cast<const uint4*>(reinterpret_cast<const uint32_t*>(xr) + 4 * g * D1);
+#pragma unroll
+    for (int u = 0; u < D1; ++u) {
+      const uint4 v = xv[u];
+      const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const uint32_t w = w4[e >> 1];
+        (&x[0][0])[8 * u + e] = __builtin_bit_cast(float, (e & 1) ? (w & 0xffff0000u) : (w << 16));
+      }
+    }
+  } else {
+    const float4* xv = reinterpret_cast<const float4*>(xr + 8 * g * D1);
+#pragma unroll
+    for (int u = 0; u < 2 * D1; ++u) {
+      const float4 v = xv[u];
+      (&x[0][0])[4 * u + 0] = v.x; (&x[0][0])[4 * u + 1] = v.y; (&x[0][0])[4 * u + 2] = v.z; (&x[0][0])[4 * u + 3] = v.w;
+    }
+  }
+}
+
 // One input chunk (degree L1, <= 32 channels = one K = 32 step) into NT16 16-channel tiles of output degree L3.
-// `xr`: this lane's row in the staged chunk; `whi`/`wlo`: packed weights at (block 2*wblk + g', channel lane & 15) of
+// `x`: the lane's operand slice (load_x16); `whi`/`wlo`: packed weights at (block 2*wblk + g', channel lane & 15) of
 // tile 0; `live`: this lane's k group lies inside the (16-padded) chunk -- otherwise its features are zero.
 template <int L1, int L2, int L3, int NT16, bool IO16>
-__device__ __forceinline__ void run16(const float* __restrict__ xr, const bool live, const int g,
+__device__ __forceinline__ void run16(const float (&x)[8][2 * L1 + 1], const bool live,
                                       const uint4* __restrict__ whi, const uint4* __restrict__ wlo,
                                       const float (&y)[9], f32x4 (&acc)[NT16][2 * L3 + 1]) {
   constexpr int D1 = 2 * L1 + 1, D2 = 2 * L2 + 1, D3 = 2 * L3 + 1;
@@ -64,27 +91,6 @@ __device__ __forceinline__ void run16(const float* __restrict__ xr, const bool l
         }
       z[a][c] = live ? s : 0.f;  // a dead k group contributes nothing (its x reads are clamped, not meaningful)
     }
-  float x[8][D1];
-  if constexpr (IO16) {
-    const uint4* xv = reinterpret_cast<const uint4*>(reinterpret_cast<const uint32_t*>(xr) + 4 * g * D1);
-#pragma unroll
-    for (int u = 0; u < D1; ++u) {
-      const uint4 v = xv[u];
-      const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const uint32_t w = w4[e >> 1];
-        (&x[0][0])[8 * u + e] = __builtin_bit_cast(float, (e & 1) ? (w & 0xffff0000u) : (w << 16));
-      }
-    }
-  } else {
-    const float4* xv = reinterpret_cast<const float4*>(xr + 8 * g * D1);
-#pragma unroll
-    for (int u = 0; u < 2 * D1; ++u) {
-      const float4 v = xv[u];
-      (&x[0][0])[4 * u + 0] = v.x; (&x[0][0])[4 * u + 1] = v.y; (&x[0][0])[4 * u + 2] = v.z; (&x[0][0])[4 * u + 3] = v.w;
-    }
-  }
 #pragma unroll
   for (int c = 0; c < D3; ++c) {
     float f[8];
@@ -320,12 +326,14 @@ __global__ __launch_bounds__(256, 2) void tp_fwd_mfma_r16_kernel(SegArgs segs, c
       const bool live = 8 * g < cpad;          // k group inside the padded chunk
       const int gw = live ? g : (g & 1);       // keep the (unused) weight reads of a dead group inside the matrix
       const float* xrl = live ? xr : cbuf;     // and its x reads inside the buffer
+      float x[8][2 * L1 + 1];
+      load_x16<L1, IO16>(xrl, live ? g : 0, x);
 #define E3_RUN(L2v, L3v, ACC, NTv)                                                                             \
   if constexpr (Slots::valid(L1, L2v, L3v)) {                                                                  \
     static_assert(CG<L1, L2v, L3v>::valid, "path bookkeeping");                                                \
     const size_t o = (size_t)(cBfoff[L3v] >> 3) + (size_t)(2 * ch.wblk[L2v][L3v] + gw) * cMpad[L3v] + j;       \
     if (!(dbg & 4))                                                                                            \
-      run16<L1, L2v, L3v, 2 * NTv, IO16>(xrl, live, live ? g : 0, whi_base + o, wlo_base + o, y, ACC);         \
+      run16<L1, L2v, L3v, 2 * NTv, IO16>(x, live, whi_base + o, wlo_base + o, y, ACC);                          \
   }
       E3_RUN(0, 0, a0, NT0) E3_RUN(1, 0, a0, NT0) E3_RUN(2, 0, a0, NT0)
       E3_RUN(0, 1, a1, NT1) E3_RUN(1, 1, a1, NT1) E3_RUN(2, 1, a1, NT1)
@@ -501,16 +509,18 @@ static const std::vector<R16KernelEntry>& r16_kernels() {
   return k;
 }
 
-static bool r16_enabled() {
-  static const bool on = [] { const char* e = getenv("E3_TP_R16"); return e && atoi(e) != 0; }();
-  return on;
+// E3_TP_R16: 0 = off, 1 (default) = fp32 storage only (measured: step 199.7 -> 184.4 ms against the two-wave kernel; for
+// bf16 storage the two-wave kernel is 1 % faster), 2 = both storage types
+static int r16_level() {
+  static const int lv = [] { const char* e = getenv("E3_TP_R16"); return e ? atoi(e) : 1; }();
+  return lv;
 }
 
 // 1 = launched, 0 = not applicable, < 0 = -status
 int fast_forward_r16(const TpFast* F, const void* sa_, const void* in2, int64_t ld2, const void* packed, void* out,
                      int64_t ldo, int64_t B, int gate, int mode, const int32_t* ocol_tab, hipStream_t s) {
   const bool scat = static_cast<const SegArgs*>(sa_)->scatter != nullptr;
-  if (!r16_enabled() || mode < 1) return 0;
+  if (mode < 1 || r16_level() < (mode == 2 ? 2 : 1)) return 0;
   const FDev& d = mode == 2 ? F->dev16 : F->dev;
   std::vector<int> l1s;
   for (auto& c : F->h_chunks) {

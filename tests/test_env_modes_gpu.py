@@ -37,10 +37,11 @@ assert err < 1e-4, err
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [
-    {"E3_TP_AB": "0"},                              # one wave per tile (the kernel of e3_tp_mfma.hip)
-    {"E3_TP_AB": "0", "E3_TP_EXACT": "1"},          # exact fp32 MFMA operands
-    {"E3_FUSED_SCATTER": "0"},                      # two-wave kernel, separate (reproducible) segment-sum
-    {"E3_TP_AB": "0", "E3_TP_NBUF": "2"},           # double-buffered staging
+    {"E3_TP_R16": "0", "E3_TP_AB": "0"},                      # one wave per 32-row tile (e3_tp_mfma.hip)
+    {"E3_TP_R16": "0", "E3_TP_AB": "0", "E3_TP_EXACT": "1"},  # exact fp32 MFMA operands
+    {"E3_TP_R16": "0"},                                       # two waves per 32-row tile (e3_tp_mfma_ab.hip)
+    {"E3_FUSED_SCATTER": "0"},                                # default kernel, separate (reproducible) segment-sum
+    {"E3_TP_R16": "0", "E3_TP_AB": "0", "E3_TP_NBUF": "2"},   # double-buffered staging
 ])
 def test_kernel_selection_modes(env):
     e = dict(os.environ)
