@@ -503,8 +503,12 @@ struct R16KernelEntry {
    SC ? (const void*)tp_fwd_mfma_r16_kernel<LSH, a, b, c, true, 1, SC, __VA_ARGS__> : nullptr}
 static const std::vector<R16KernelEntry>& r16_kernels() {
   static const std::vector<R16KernelEntry> k = {
-      E3_R16(2, 3, 1, 1, false, 0, 1, 2, 0, 1, 2, 0),  // message TP #1
-      E3_R16(2, 3, 1, 1, true, 0, 1, 2),               // message TP #2 (+ fused segment-sum)
+      E3_R16(2, 3, 1, 1, false, 0, 1, 2, 0, 1, 2, 0),  // l_max 2: message TP #1
+      E3_R16(2, 3, 1, 1, true, 0, 1, 2),               //          message TP #2 (+ fused segment-sum)
+      E3_R16(2, 3, 1, 1, false, 0, 1, 2, 0, 1, 2),     //          update TP #1
+      E3_R16(1, 2, 1, 0, false, 0, 1, 0, 1, 0),        // l_max 1: message TP #1
+      E3_R16(1, 2, 1, 0, true, 0, 1),                  //          message TP #2 (+ fused segment-sum)
+      E3_R16(1, 2, 1, 0, false, 0, 1, 0, 1),           //          update TP #1
   };
   return k;
 }
