@@ -137,8 +137,12 @@ __device__ __forceinline__ void run16(const float (&x)[8][2 * L1 + 1], const boo
 }
 
 // NT0/NT1/NT2 = 32-channel tile counts per output degree as in the other kernels (each = two 16-channel MFMA tiles)
+// waves per SIMD the register allocation is capped for: 2 with l_max = 2 outputs (88 accumulator registers), 3 with the
+// l_max = 1 products (40)
+constexpr int r16_waves_per_simd(int nt2) { return nt2 > 0 ? 2 : 3; }
+
 template <int LSH, int NT0, int NT1, int NT2, bool GATE, int MODE, bool SCAT, int... L1S>
-__global__ __launch_bounds__(256, 2) void tp_fwd_mfma_r16_kernel(SegArgs segs, const float* __restrict__ in2, int64_t ld2,
+__global__ __launch_bounds__(256, r16_waves_per_simd(NT2)) void tp_fwd_mfma_r16_kernel(SegArgs segs, const float* __restrict__ in2, int64_t ld2,
                                                                   const float* __restrict__ packed, void* __restrict__ outv,
                                                                   int64_t ldo, int64_t B, const FDev* __restrict__ dp,
                                                                   const FChunk* __restrict__ chunks,
@@ -541,14 +545,14 @@ int fast_forward_r16(const TpFast* F, const void* sa_, const void* in2, int64_t 
   const size_t per_wave = (size_t)((mode == 2 ? kChunkR16h : kChunkR16) + 160) * 4;
   const int nwaves = 4;  // per workgroup; two workgroups per CU
   const size_t lds_bytes = tables + nwaves * per_wave;
-  if (2 * lds_bytes > (size_t)kFastLds) return 0;
+  if ((size_t)r16_waves_per_simd(d.NT[2]) * lds_bytes > (size_t)kFastLds) return 0;
   static std::vector<const void*> configured;
   if (std::find(configured.begin(), configured.end(), fn) == configured.end()) {
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return -E3_ERR_HIP;
     configured.push_back(fn);
   }
   const int64_t ntiles = (B + 15) / 16;
-  const int grid = (int)std::min<int64_t>((ntiles + nwaves - 1) / nwaves, 256 * 2);
+  const int grid = (int)std::min<int64_t>((ntiles + nwaves - 1) / nwaves, 256 * r16_waves_per_simd(d.NT[2]));
   const float* in2f = (const float*)in2;
   const float* pk = (const float*)packed;
   void* outf = out;
