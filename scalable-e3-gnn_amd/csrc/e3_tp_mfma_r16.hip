@@ -30,8 +30,6 @@ __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
-constexpr int kChunkR16 = 16 * 41 * 4;     // fp32 storage: 16 rows x 41 16-byte units (= 16 x 164 dwords: also the out tile)
-constexpr int kChunkR16h = 16 * (32 * 5 + 4);  // bf16 storage: sized by the out tile (16 rows x 164 dwords)
 
 // this lane's operand slice of a staged chunk: 8 channels (k group g) x D1 components, read ONCE per chunk and shared
 // by every path of the chunk
@@ -139,7 +137,9 @@ __device__ __forceinline__ void run16(const float (&x)[8][2 * L1 + 1], const boo
 // NT0/NT1/NT2 = 32-channel tile counts per output degree as in the other kernels (each = two 16-channel MFMA tiles)
 // waves per SIMD the register allocation is capped for: 2 with l_max = 2 outputs (88 accumulator registers), 3 with the
 // l_max = 1 products (40)
-constexpr int r16_waves_per_simd(int nt2) { return nt2 > 0 ? 2 : 3; }
+constexpr int r16_waves_per_simd(int nt2) { return nt2 > 0 ? 2 : 3; }  // (4 spills 24-49 VGPRs: 61 -> 66 ms)
+// per-wave chunk buffer (dwords): the larger of a staged chunk and the out tile -- 16 rows x (32 ch x D + 4), D = 5 / 3
+constexpr int r16_chunk(int nt2) { return 16 * (32 * (nt2 > 0 ? 5 : 3) + 4); }
 
 template <int LSH, int NT0, int NT1, int NT2, bool GATE, int MODE, bool SCAT, int... L1S>
 __global__ __launch_bounds__(256, r16_waves_per_simd(NT2)) void tp_fwd_mfma_r16_kernel(SegArgs segs, const float* __restrict__ in2, int64_t ld2,
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256, r16_waves_per_simd(NT2)) void tp_fwd_mfma_r16_
                                                                   const int32_t* __restrict__ ocol_tab) {
   static_assert(MODE == 1 || MODE == 2, "bf16-pipe modes only");
   constexpr bool IO16 = MODE == 2;
-  constexpr int CHUNK = IO16 ? kChunkR16h : kChunkR16;
+  constexpr int CHUNK = r16_chunk(NT2);
   extern __shared__ __align__(16) unsigned char smem_raw[];
   float* lds = reinterpret_cast<float*>(smem_raw);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -542,7 +542,7 @@ int fast_forward_r16(const TpFast* F, const void* sa_, const void* in2, int64_t 
   if (scat && (mode != 1 || !gate || !e->fn_scat)) return 0;
   const void* fn = scat ? e->fn_scat : e->fn[mode - 1][gate ? 1 : 0];
   const size_t tables = (size_t)(((d.Dout + 4 + 15) & ~15) + ((d.ntab + 15) & ~15)) * 4;
-  const size_t per_wave = (size_t)((mode == 2 ? kChunkR16h : kChunkR16) + 160) * 4;
+  const size_t per_wave = (size_t)(r16_chunk(d.NT[2]) + 160) * 4;
   const int nwaves = 4;  // per workgroup; two workgroups per CU
   const size_t lds_bytes = tables + nwaves * per_wave;
   if ((size_t)r16_waves_per_simd(d.NT[2]) * lds_bytes > (size_t)kFastLds) return 0;
