@@ -235,6 +235,9 @@ int e3_tp_backward(const e3_tp_plan* plan, const void* in1, int64_t ld_in1, cons
                    const void* packed, const void* grad_out, int64_t ld_gout, void* grad_in1, int64_t ld_gin1,
                    void* grad_in2, int64_t ld_gin2, void* const grad_weights[6], int64_t B, int dtype, void* stream);
 int e3_tp_fused_supported(const e3_tp_plan* plan, int gate);
+/* kernel family ("e3::tp_fwd_mfma_r16_kernel" / "..._ab_kernel" / "..._kernel") that this thread's most recent
+ * e3_tp_forward_fused / _scatter / MFMA e3_tp_forward call launched; "" before the first one (diagnostics, bench labels) */
+const char* e3_tp_last_fused_kernel(void);
 /* e3_tp_forward_fused with the message pass's segment-sum fused into the epilogue: row b of the (gated) product is not
  * stored but ADDED to out_nodes[row_node[b]] (fp32 atomics; row_node ascending, e.g. the dst column of a CSR-by-dst
  * edge list; out_nodes zero-initialised by the caller, ld_out a multiple of 4 elements, 16-byte aligned).  The

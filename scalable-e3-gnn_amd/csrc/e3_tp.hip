@@ -666,6 +666,8 @@ int e3_tp_backward(const e3_tp_plan* plan, const void* in1, int64_t ld1, const v
                                                  grad_in2, ldg2, gw, B, s);
 }
 
+const char* e3_tp_last_fused_kernel(void) { return fast_last_kernel(); }
+
 // diagnostic: per-phase wave-cycle sums of the MFMA kernel (E3_TP_DBG & 8); reads and clears
 int e3_tp_debug_phase_cycles(const e3_tp_plan* plan, unsigned long long out[8]) {
   if (!plan || !out || !plan->fast.dev.prof) return E3_ERR_UNSUPPORTED;

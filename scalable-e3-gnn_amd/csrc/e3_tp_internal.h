@@ -57,6 +57,10 @@ int fast_forward(const TpFast* F, const e3_tp_segment* segs, int nseg, int D1, c
                  const void* packed, void* out, int64_t ldo, int64_t B, int gate, int dtype, const int32_t* ocol_tab,
                  hipStream_t s, const int32_t* scatter = nullptr);
 
+// name of the kernel family the last fused forward of this thread launched (diagnostics / bench labels)
+void fast_note_kernel(const char* name);
+const char* fast_last_kernel();
+
 // two-waves-per-tile kernel (e3_tp_mfma_ab.hip): 1 = launched, 0 = no instantiation / disabled, < 0 = -status
 int fast_forward_ab(const TpFast* F, const void* seg_args, const void* in2, int64_t ld2, const void* packed, void* out,
                     int64_t ldo, int64_t B, int gate, int mode, const int32_t* ocol_tab, hipStream_t s);

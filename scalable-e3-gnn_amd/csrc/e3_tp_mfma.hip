@@ -244,6 +244,10 @@ int fast_pack(const TpFast* F, const void* const w[6], const void* const n[6], i
   return E3_OK;
 }
 
+static thread_local const char* g_last_kernel = "";
+void fast_note_kernel(const char* name) { g_last_kernel = name; }
+const char* fast_last_kernel() { return g_last_kernel; }
+
 int fast_forward(const TpFast* F, const e3_tp_segment* segs, int nseg, int D1, const void* in2, int64_t ld2,
                  const void* packed, void* out, int64_t ldo, int64_t B, int gate, int dtype, const int32_t* ocol_tab,
                  hipStream_t s, const int32_t* scatter) {
@@ -302,6 +306,7 @@ int fast_forward(const TpFast* F, const e3_tp_segment* segs, int nseg, int D1, c
   void* args[] = {&sa, &in2f, &ld2, &pk, &outf, &ldo, &B, &dd, &dc, &ocol_tab};
   E3_HIP_CHECK(hipLaunchKernel(e->fn[mode][d.w_in_lds ? 1 : 0][gate ? 1 : 0], dim3(grid), dim3(64 * d.nwaves), args,
                                lds_bytes, s));
+  fast_note_kernel("e3::tp_fwd_mfma_kernel");
   return E3_OK;
 }
 

@@ -560,6 +560,7 @@ int fast_forward_r16(const TpFast* F, const void* sa_, const void* in2, int64_t 
   const FChunk* dc = F->d_chunks;
   void* args[] = {const_cast<void*>(sa_), &in2f, &ld2, &pk, &outf, &ldo, &B, &dd, &dc, &ocol_tab};
   if (hipLaunchKernel(fn, dim3(grid), dim3(64 * nwaves), args, lds_bytes, s) != hipSuccess) return -E3_ERR_HIP;
+  fast_note_kernel("e3::tp_fwd_mfma_r16_kernel");
   return 1;
 }
 

@@ -164,7 +164,7 @@ class TPPlan:
                 mode = ("<bf16 storage, bf16 MFMA>" if io == torch.bfloat16 else
                         "<exact fp32 MFMA>" if os.environ.get("E3_TP_EXACT") else "<bf16x3 split MFMA>")
                 profiling.end(f"tp_fused{'+segsum' if scatter is not None else ''} {tag} B={B}", B, nb, t0, flops=self.flops_per_row * B,
-                              kernel="e3::tp_fwd_mfma_kernel" + mode)
+                              kernel=(lib.e3_tp_last_fused_kernel() or b"e3::tp_fwd_mfma_kernel").decode() + mode)
         return out
 
 
