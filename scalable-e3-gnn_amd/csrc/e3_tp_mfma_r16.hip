@@ -138,8 +138,14 @@ __device__ __forceinline__ void run16(const float (&x)[8][2 * L1 + 1], const boo
 // waves per SIMD the register allocation is capped for: 2 with l_max = 2 outputs (88 accumulator registers), 3 with the
 // l_max = 1 products (40)
 constexpr int r16_waves_per_simd(int nt2) { return nt2 > 0 ? 2 : 3; }  // (4 spills 24-49 VGPRs: 61 -> 66 ms)
-// per-wave chunk buffer (dwords): the larger of a staged chunk and the out tile -- 16 rows x (32 ch x D + 4), D = 5 / 3
-constexpr int r16_chunk(int nt2) { return 16 * (32 * (nt2 > 0 ? 5 : 3) + 4); }
+// per-wave chunk buffer (dwords): the larger of a staged chunk (input degree lin) and the out tile (output degree lout):
+// 16 rows x (32 channels x (2l + 1) + 4)
+constexpr int r16_chunk(int lin, int lout) { return 16 * (32 * (2 * (lin > lout ? lin : lout) + 1) + 4); }
+constexpr int r16_max(std::initializer_list<int> v) {
+  int m = 0;
+  for (int x : v) m = x > m ? x : m;
+  return m;
+}
 
 template <int LSH, int NT0, int NT1, int NT2, bool GATE, int MODE, bool SCAT, int... L1S>
 __global__ __launch_bounds__(256, r16_waves_per_simd(NT2)) void tp_fwd_mfma_r16_kernel(SegArgs segs, const float* __restrict__ in2, int64_t ld2,
@@ -149,7 +155,7 @@ __global__ __launch_bounds__(256, r16_waves_per_simd(NT2)) void tp_fwd_mfma_r16_
                                                                   const int32_t* __restrict__ ocol_tab) {
   static_assert(MODE == 1 || MODE == 2, "bf16-pipe modes only");
   constexpr bool IO16 = MODE == 2;
-  constexpr int CHUNK = r16_chunk(NT2);
+  constexpr int CHUNK = r16_chunk(r16_max({L1S...}), NT2 > 0 ? 2 : (NT1 > 0 ? 1 : 0));
   extern __shared__ __align__(16) unsigned char smem_raw[];
   float* lds = reinterpret_cast<float*>(smem_raw);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -513,6 +519,11 @@ static const std::vector<R16KernelEntry>& r16_kernels() {
       E3_R16(1, 2, 1, 0, false, 0, 1, 0, 1, 0),        // l_max 1: message TP #1
       E3_R16(1, 2, 1, 0, true, 0, 1),                  //          message TP #2 (+ fused segment-sum)
       E3_R16(1, 2, 1, 0, false, 0, 1, 0, 1),           //          update TP #1
+      E3_R16(2, 1, 1, 1, false, 0, 1, 2),              // l_max 2: update TP #2
+      E3_R16(2, 1, 1, 1, false, 0, 1),                 //          embedding
+      E3_R16(2, 0, 1, 0, false, 0, 1, 2),              //          readout
+      E3_R16(1, 1, 1, 0, false, 0, 1),                 // l_max 1: update TP #2 / embedding
+      E3_R16(1, 0, 1, 0, false, 0, 1),                 //          readout
   };
   return k;
 }
@@ -539,10 +550,16 @@ int fast_forward_r16(const TpFast* F, const void* sa_, const void* in2, int64_t 
   for (auto& k : r16_kernels())
     if (k.lsh == d.lsh && k.nt0 == d.NT[0] && k.nt1 == d.NT[1] && k.nt2 == d.NT[2] && k.l1s == l1s) e = &k;
   if (!e) return 0;
+  {  // diagnostic: E3_R16_MASK bit i disables table entry i
+    static const int mask = [] { const char* m = getenv("E3_R16_MASK"); return m ? atoi(m) : 0; }();
+    if (mask & (1 << (int)(e - r16_kernels().data()))) return 0;
+  }
   if (scat && (mode != 1 || !gate || !e->fn_scat)) return 0;
   const void* fn = scat ? e->fn_scat : e->fn[mode - 1][gate ? 1 : 0];
   const size_t tables = (size_t)(((d.Dout + 4 + 15) & ~15) + ((d.ntab + 15) & ~15)) * 4;
-  const size_t per_wave = (size_t)(r16_chunk(d.NT[2]) + 160) * 4;
+  int lin = 0;
+  for (int l : l1s) lin = std::max(lin, l);
+  const size_t per_wave = (size_t)(r16_chunk(lin, d.NT[2] > 0 ? 2 : (d.NT[1] > 0 ? 1 : 0)) + 160) * 4;
   const int nwaves = 4;  // per workgroup; two workgroups per CU
   const size_t lds_bytes = tables + nwaves * per_wave;
   if ((size_t)r16_waves_per_simd(d.NT[2]) * lds_bytes > (size_t)kFastLds) return 0;

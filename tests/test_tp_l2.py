@@ -61,6 +61,9 @@ def test_oracle_reduces_to_l1tp_oracle():
     ("8x0e+8x1o+8x2e", "8x0e+8x1o+8x2e", 2, "float32"),
     ("3x0e+2x0o+4x1o+5x1e+2x2e+3x2o", "6x0e+2x0o+3x1e+7x1o+2x2o+3x2e", 2, "float64"),
     ("32x0e+32x1o+32x2e+32x0e+32x1o+32x2e+1x0e", "96x0e+32x1o+32x2e", 2, "float32"),
+    ("32x0e+32x1o+32x2e", "1x1o", 2, "float32"),            # readout shape: l=2 inputs, one l=1 output channel
+    ("1x0e+1x1o", "32x0e+32x1o+32x2e", 2, "float32"),       # embedding shape: single-channel input chunks
+    ("32x0e+32x1o", "1x1o", 1, "float32"),
 ])
 def test_gpu_forward_vs_oracle(in1, out, lmax_sh, dtype):
     from scalable_e3_gnn_amd.tensor_product import SHTensorProduct
