@@ -89,6 +89,51 @@ __device__ __forceinline__ void run16(const float (&x)[8][2 * L1 + 1], const boo
         }
       z[a][c] = live ? s : 0.f;  // a dead k group contributes nothing (its x reads are clamped, not meaningful)
     }
+  if constexpr (L1 == 0 && D3 > 1) {
+    // scalar input channels into a vector output: out[c] = z[0][c] * (W . x) -- contract the raw channels ONCE into a
+    // temporary tile and fold with z afterwards (one feature build and one MFMA group instead of D3 of each)
+    uint32_t ph[4], pl[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float f0 = live ? x[2 * q][0] : 0.f, f1 = live ? x[2 * q + 1][0] : 0.f;
+      ph[q] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{f0, f1}, bf16x2_t));
+      if constexpr (!IO16) {
+        const float h0 = __builtin_bit_cast(float, ph[q] << 16), h1 = __builtin_bit_cast(float, ph[q] & 0xffff0000u);
+        pl[q] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{f0 - h0, f1 - h1}, bf16x2_t));
+      }
+    }
+    const bf16x8 bh = __builtin_bit_cast(bf16x8, uint4{ph[0], ph[1], ph[2], ph[3]});
+    f32x4 T[NT16];
+#pragma unroll
+    for (int t = 0; t < NT16; ++t) T[t] = mfma16(__builtin_bit_cast(bf16x8, ah[t]), bh, f32x4{0.f, 0.f, 0.f, 0.f});
+    if constexpr (!IO16) {
+      const bf16x8 bl = __builtin_bit_cast(bf16x8, uint4{pl[0], pl[1], pl[2], pl[3]});
+#pragma unroll
+      for (int t = 0; t < NT16; ++t) T[t] = mfma16(__builtin_bit_cast(bf16x8, ah[t]), bl, T[t]);
+#pragma unroll
+      for (int t = 0; t < NT16; ++t) T[t] = mfma16(__builtin_bit_cast(bf16x8, al[t]), bh, T[t]);
+    }
+    // z of THIS lane's row scales its own accumulator column: the output tile holds channels x (this lane's row)
+    float zr[D3];
+#pragma unroll
+    for (int c = 0; c < D3; ++c) {
+      float sz = 0.f;
+      bool have = false;
+#pragma unroll
+      for (int b = 0; b < D2; ++b)
+        if (C::v[0][b][c] != 0.0) {
+          sz = have ? __builtin_fmaf((float)C::v[0][b][c], y[L2 * L2 + b], sz) : (float)C::v[0][b][c] * y[L2 * L2 + b];
+          have = true;
+        }
+      zr[c] = sz;
+    }
+#pragma unroll
+    for (int t = 0; t < NT16; ++t)
+#pragma unroll
+      for (int c = 0; c < D3; ++c) acc[t][c] += T[t] * zr[c];
+    __builtin_amdgcn_sched_barrier(0);
+    return;
+  }
 #pragma unroll
   for (int c = 0; c < D3; ++c) {
     float f[8];
