@@ -551,6 +551,28 @@ __device__ __forceinline__ void run_steps_io16_lean(const uint32_t* __restrict__
   uint4 ah[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) ah[t] = pre_h[t];
+  if constexpr (L1 == 0 && D3 > 1) {
+    // scalar input channels into a vector output: contract the raw bf16 channels once (they ARE the B operand: no
+    // VALU at all in the k loop) into a temporary tile, fold with z afterwards
+    f32x16 T[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) T[t] = f32x16{0};
+    for (int kb = 0; kb < nkb; ++kb) {
+      const uint4 xv = *reinterpret_cast<const uint4*>(xp + 8 * kb);
+      const bf16x8 bh = __builtin_bit_cast(bf16x8, xv);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        T[t] = mfma_bf16(__builtin_bit_cast(bf16x8, ah[t]), bh, T[t]);
+        if (kb + 1 < nkb) ah[t] = whi[(2 * (kb + 1)) * Mpad + 32 * t];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int c = 0; c < D3; ++c) acc[t][c] += T[t] * z[0][c];
+    __builtin_amdgcn_sched_barrier(0);
+    return;
+  }
   for (int kb = 0; kb < nkb; ++kb) {
     uint4 ahn[NT];
     if (kb + 1 < nkb) {
