@@ -204,7 +204,7 @@ def main():
         # the bounding roofline of this kernel = whichever limit gives the longer minimum time
         # bf16x3 split kernel: every fp32 product is executed as 3 bf16 MFMA products (hi*hi + hi*lo + lo*hi) -> the
         # matrix pipe sees 3x the algorithmic flops and its peak is the bf16 dense peak
-        split = "bf16x3" in dom["kernel"]
+        split = "x3 split" in dom["kernel"]
         native16 = "bf16 storage" in dom["kernel"]
         mfma_peak = MFMA_BF16_PEAK_TF if (split or native16) else MFMA_F32_PEAK_TF
         exec_mult = 3.0 if split else 1.0
@@ -217,7 +217,7 @@ def main():
                 "achieved": tfs * exec_mult if mfma_bound else gbs, "peak": mfma_peak if mfma_bound else HBM_PEAK_GBS,
                 "unit": "TFLOP/s" if mfma_bound else "GB/s",
                 "frac": (tfs * exec_mult / mfma_peak) if mfma_bound else (gbs / HBM_PEAK_GBS), "traffic": traffic,
-                "mfma_mode": ("bf16x3 split (3 bf16 MFMA products per fp32 product, fp32 accumulate)" if split else
+                "mfma_mode": ("fp16x3 split (3 f16 MFMA products per fp32 product: hi*hi + hi*lo + lo*hi, fp32 accumulate)" if split else
                               "bf16 operands, fp32 accumulate" if native16 else "fp32"),
                 "fp32_equivalent_TFLOPps": tfs, "fp32_equivalent_frac_of_157.3": tfs / MFMA_F32_PEAK_TF,
                 "avg_launch_ms": dom["avg_ms"], "launches": dom["launches"],

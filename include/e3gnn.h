@@ -210,11 +210,30 @@ int e3_tp_norm_len(const e3_tp_plan* plan, int cls);
 int64_t e3_tp_packed_bytes(const e3_tp_plan* plan, int dtype);
 int e3_tp_pack_weights(const e3_tp_plan* plan, const void* const weights[6], const void* const norms[6],
                        int dtype, void* packed, void* stream);
-/* dtype E3_F32 / E3_F64 (in2 of the same type; ld_in2 == 0 broadcasts row 0) or E3_BF16 (in2 fp32, see below) */
+/* dtype E3_F32 / E3_F64 (in2 of the same type; ld_in2 == 0 broadcasts row 0) or E3_BF16 (in2 fp32, see below).
+ * E3_F32 runs on the matrix cores where the plan has an MFMA instantiation (fp16 (hi, lo)-split operands, fp32
+ * accumulation: ~2^-21 per product, see "Operand scales" below); `exact` != 0 forces the generic fp32 FMA kernel.
+ * in_scale: device pointer to {s, 1/s} from e3_pow2_scale (NULL = 1: inputs must then lie in about [2^-3, 2^12]). */
 int e3_tp_forward(const e3_tp_plan* plan, const void* in1, int64_t ld_in1, const void* in2, int64_t ld_in2,
-                  const void* packed, void* out, int64_t ld_out, int64_t B, int dtype, void* stream);
+                  const void* packed, void* out, int64_t ld_out, int64_t B, int dtype, const float* in_scale,
+                  int exact, void* stream);
 /*
- * Fused message-function form (fp32 MFMA kernel, natural-parity irreps 0e/1o/2e only):
+ * Operand scales.  The fp32-storage MFMA kernels split every fp32 operand into two fp16 halves (hi = rne16(v),
+ * lo = rne16(v - hi)) and accumulate hi*hi + hi*lo + lo*hi in fp32 on v_mfma_f32_16x16x32_f16.  hi + lo carries 22
+ * significant bits while lo is a normal fp16 number, so tensors are multiplied by a power of two that puts their largest
+ * magnitude at 2^target (weights: at pack time, 2^13; input features: `in_scale`, 2^10 -- the per-row CG / SH factors
+ * add < 2^4).  e3_pow2_scale reduces max |x| over up to 4 fp32 tensors (segs[i].base/ld/ncols x nrows[i]; row_index
+ * ignored) and writes out4 = {s, 1/s, scratch, scratch} on the stream; no host synchronisation.  Exact powers of two:
+ * scaling itself adds no rounding.  e3_add_pow2_scale: out = h + u (n elements, n % 4 == 0, 16-byte aligned) and the
+ * scale of `out` in the same pass (the residual update of a layer yields the next layer's scale for free).
+ */
+int e3_pow2_scale(const e3_tp_segment* segs, const int64_t* nrows, int nseg, int target_log2, float* out4,
+                  void* stream);
+int e3_add_pow2_scale(const float* h, const float* u, float* out, int64_t n, int target_log2, float* out4,
+                      void* stream);
+/*
+ * Fused gather + concat (+ gate) form (MFMA kernel, natural-parity irreps 0e/1o/2e only; one plan belongs to the device
+ * that was current at its first use -- a call with another current device returns E3_ERR_INVALID_ARG):
  *   in1[b] = [ seg0.base[idx0[b]] | seg1.base[idx1[b]] | ... ]   (the gather and the concat never reach HBM;
  *            segment boundaries must fall on irreps-block boundaries, at most 4 segments)
  *   gate != 0: out irreps must be [32x0e | 32x0e per gated block | 32x1o | 32x2e]; the kernel writes
@@ -224,7 +243,7 @@ int e3_tp_forward(const e3_tp_plan* plan, const void* in1, int64_t ld_in1, const
  */
 int e3_tp_forward_fused(const e3_tp_plan* plan, const e3_tp_segment* segs, int nseg,
                         const void* in2, int64_t ld_in2, const void* packed, void* out, int64_t ld_out,
-                        int64_t B, int dtype, int gate, void* stream);
+                        int64_t B, int dtype, int gate, const float* in_scale, void* stream);
 /* Gradients of e3_tp_forward (fp32 / fp64; the reference operator relies on torch autograd, l1_tensor_prod.py:240-299).
  * `packed` = the buffer e3_tp_pack_weights wrote for this dtype.  Any of grad_in1 [B, in1_dim] (storage dtype),
  * grad_in2 [B, in2_dim] (ACCUMULATION dtype: fp32 for E3_F32, fp64 for E3_F64; with broadcast in2, ld_in2 == 0, pass
@@ -235,7 +254,7 @@ int e3_tp_backward(const e3_tp_plan* plan, const void* in1, int64_t ld_in1, cons
                    const void* packed, const void* grad_out, int64_t ld_gout, void* grad_in1, int64_t ld_gin1,
                    void* grad_in2, int64_t ld_gin2, void* const grad_weights[6], int64_t B, int dtype, void* stream);
 int e3_tp_fused_supported(const e3_tp_plan* plan, int gate);
-/* kernel family ("e3::tp_fwd_mfma_r16_kernel" / "..._ab_kernel" / "..._kernel") that this thread's most recent
+/* kernel family ("e3::tp_fwd_mfma_r16_kernel") that this thread's most recent
  * e3_tp_forward_fused / _scatter / MFMA e3_tp_forward call launched; "" before the first one (diagnostics, bench labels) */
 const char* e3_tp_last_fused_kernel(void);
 /* e3_tp_forward_fused with the message pass's segment-sum fused into the epilogue: row b of the (gated) product is not
@@ -247,14 +266,11 @@ const char* e3_tp_last_fused_kernel(void);
  * plan has no two-wave instantiation with this epilogue (callers then run the two kernels). */
 int e3_tp_forward_fused_scatter(const e3_tp_plan* plan, const e3_tp_segment* segs, int nseg,
                                 const void* in2, int64_t ld_in2, const void* packed, const int32_t* row_node,
-                                void* out_nodes, int64_t ld_out, int64_t B, int dtype, int gate, void* stream);
-/* diagnostic (E3_TP_DBG & 8 at plan creation): wave-cycle sums per kernel phase since the last call:
- * [0] tile prologue issue, [1] waiting for staged data, [2] staging issue, [3] MFMA runs, [4] epilogue: gate +
- * transpose into LDS, [5] epilogue: norm + stores, [6..7] unused */
-int e3_tp_debug_phase_cycles(const e3_tp_plan* plan, unsigned long long out[8]);
+                                void* out_nodes, int64_t ld_out, int64_t B, int dtype, int gate,
+                                const float* in_scale, void* stream);
 /*
  * bf16 storage (dtype E3_BF16, BASELINE config 3): segments / in1 / out / weights / norms are bf16, in2 (the
- * spherical harmonics) stays fp32, products run once on v_mfma_f32_32x32x16_bf16 with fp32 accumulation and one
+ * spherical harmonics) stays fp32, products run once on v_mfma_f32_16x16x32_bf16 with fp32 accumulation and one
  * rounding of the result.  Only the MFMA path exists for bf16 (E3_ERR_UNSUPPORTED otherwise).
  */
 int e3_segment_sum_bf16(const void* msg, int64_t ld_msg, const int32_t* rowptr, int64_t N, int D,

@@ -58,16 +58,17 @@ SIGNATURES = {
     "e3_tp_packed_bytes": (c_int64, [c_void_p, c_int]),
     "e3_tp_pack_weights": (c_int, [c_void_p, c_void_p * 6, c_void_p * 6, c_int, c_void_p, c_void_p]),
     "e3_tp_forward": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64,
-                              c_int, c_void_p]),
+                              c_int, c_void_p, c_int, c_void_p]),
     "e3_tp_forward_fused": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64,
-                                    c_int, c_int, c_void_p]),
+                                    c_int, c_int, c_void_p, c_void_p]),
+    "e3_pow2_scale": (c_int, [c_void_p, POINTER(c_int64), c_int, c_int, c_void_p, c_void_p]),
+    "e3_add_pow2_scale": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "e3_tp_backward": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
                                c_int64, c_void_p, c_int64, c_void_p * 6, c_int64, c_int, c_void_p]),
     "e3_tp_fused_supported": (c_int, [c_void_p, c_int]),
     "e3_tp_last_fused_kernel": (ctypes.c_char_p, []),
     "e3_tp_forward_fused_scatter": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
-                                            c_int64, c_int64, c_int, c_int, c_void_p]),
-    "e3_tp_debug_phase_cycles": (c_int, [c_void_p, c_void_p]),
+                                            c_int64, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "e3_segment_sum_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p]),
     "e3_edge_geometry_l2": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "e3_gate_blocks": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, POINTER(c_int32),
@@ -126,3 +127,56 @@ def dtype_code(dtype) -> int:
         return {torch.float32: E3_F32, torch.float64: E3_F64, torch.bfloat16: E3_BF16}[dtype]
     except KeyError:
         raise RuntimeError(f"libe3gnn_hip supports float32 / float64 / bfloat16, got {dtype}") from None
+
+
+class DevicePlans:
+    """Plan handles of one operator, one per device (a C plan keeps its tables on the device that was current at its
+    first use and rejects calls from any other).  Holds only the constructor arguments as state: ``copy.deepcopy``,
+    ``pickle`` and ``torch.save(module)`` rebuild an empty holder, and handles are created lazily -- two owners never
+    share (and double-free) a handle."""
+
+    def __init__(self, create_name: str, destroy_name: str, *args):
+        self._create, self._destroy_name, self._args = create_name, destroy_name, args
+        self._handles = {}
+
+    def _make(self):
+        lib = load()
+        cargs = []
+        for a in self._args:
+            if isinstance(a, (list, tuple)):
+                arr, n = blocks_array(a)
+                cargs += [arr, n]
+            else:
+                cargs.append(int(a))
+        h = c_void_p()
+        check(getattr(lib, self._create)(*cargs, ctypes.byref(h)), self._create)
+        return h
+
+    def handle(self, device=None) -> c_void_p:
+        """The handle for ``device`` (a torch.device / index; None = a host-only handle for shape queries)."""
+        key = -1
+        if device is not None:
+            import torch
+            key = torch.device(device).index
+            if key is None:
+                key = torch.cuda.current_device()
+        h = self._handles.get(key)
+        if h is None:
+            h = self._handles[key] = self._make()
+        return h
+
+    def __deepcopy__(self, memo):
+        return DevicePlans(self._create, self._destroy_name, *self._args)
+
+    def __reduce__(self):
+        return (DevicePlans, (self._create, self._destroy_name) + tuple(self._args))
+
+    def __del__(self):
+        try:
+            lib = load()
+            for h in self._handles.values():
+                if h:
+                    getattr(lib, self._destroy_name)(h)
+            self._handles = {}
+        except Exception:
+            pass

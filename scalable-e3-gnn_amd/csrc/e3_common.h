@@ -73,6 +73,7 @@ struct e3_l1tp_plan {
   e3::PlanDev dev;
   std::vector<int32_t> h_tables;  // [cpos (D1) | opos (Dout) | icol (sum n) | ocol (sum M)]
   int32_t* d_tables = nullptr;    // uploaded on first use
+  int device = -1;                // ... to the device current at that moment; calls from another device fail
   std::mutex mu;
   int wrows[4], wcols[4];
   int normlen[4];

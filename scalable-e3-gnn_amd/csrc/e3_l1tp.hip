@@ -346,9 +346,9 @@ namespace e3 {
 int ensure_device(const e3_l1tp_plan* cplan) {
   auto* P = const_cast<e3_l1tp_plan*>(cplan);
   std::lock_guard<std::mutex> lock(P->mu);
-  if (P->d_tables) return E3_OK;
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return E3_ERR_NO_DEVICE;
+  int ndev = 0, cur = -1;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0 || hipGetDevice(&cur) != hipSuccess) return E3_ERR_NO_DEVICE;
+  if (P->d_tables) return cur == P->device ? E3_OK : E3_ERR_INVALID_ARG;  // one plan = one device (create one per device)
   int32_t* d = nullptr;
   E3_HIP_CHECK(hipMalloc((void**)&d, P->h_tables.size() * sizeof(int32_t)));
   hipError_t e = hipMemcpy(d, P->h_tables.data(), P->h_tables.size() * sizeof(int32_t), hipMemcpyHostToDevice);
@@ -366,6 +366,7 @@ int ensure_device(const e3_l1tp_plan* cplan) {
     (void)hipFree(d);
     return st;
   }
+  P->device = cur;
   P->d_tables = d;
   return E3_OK;
 }

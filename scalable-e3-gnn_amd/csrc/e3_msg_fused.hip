@@ -1,0 +1,1031 @@
+// The SEGNN message function as ONE launch per layer (BASELINE.json north_star: "fused per-edge CDNA4 HIP kernel"):
+//
+//     a_i = sum_{e: dst(e) = i}  gate( TP2( gate( TP1( [h_dst | h_src | d_e] ; Y_e ) ) ; Y_e ) )
+//
+// per 16-edge tile and wave: spherical harmonics from the two positions, message TP #1, gate, message TP #2, gate and the
+// segment-sum over dst -- the [E, 288] messages, Y [E, 9] and d [E] never exist in HBM.  Hidden irreps Hx0e+Hx1o(+Hx2e),
+// H in {16, 32, 64}; TP semantics, weight row order and norms are those of e3_tp_* (include/e3gnn.h), i.e. of the
+// reference operator for l <= 1 (l1_tensor_prod.py:242-297).
+//
+// Formulation ("mix first"): for a path (l1, l2, l3) with weights W and coupling z[a][c] = sum_b C[a][b][c] Y_l2[b],
+//     out[c][w] = sum_a z[a][c] * u[a][w],      u[a][w] = sum_k W[k][w] x[k][a]
+// u is a plain GEMM of the RAW input channels -- the MFMA B operand is x itself, split into fp16 (hi, lo) ONCE per input
+// degree and shared by every path and tile -- and the Y-dependent part is a small per-lane fold of accumulator tiles.
+// Two consequences used here:
+//   * the dst half of TP #1 does not depend on the edge at all: u_dst = W_dst h_dst is computed once per NODE by
+//     msg_premix_kernel (1/24 of the rows) and enters the edge kernel as the initial value of the MFMA accumulator;
+//   * the gated output of TP #1 sits in accumulator layout (lane = (edge, 4 channels)), which is exactly the B-operand
+//     layout of TP #2 when the k order of the weights is permuted to match (kperm below): no transpose between them.
+// Paths into scalar outputs (l3 = 0, l1 > 0) are cheaper "feature first": f[k] = sum_a z[a] x[k][a], one MFMA group.
+//
+// MFMA: v_mfma_f32_16x16x32_f16, A = weights [16 out channels][32 k], B = features [32 k][16 edges], D = [channel 4g + r]
+// [edge j] in lane (j = lane & 15, g = lane >> 4).  fp32 products as hi*hi + hi*lo + lo*hi (split2_f16), operands scaled
+// by powers of two: weights at pack time (header), h by `in_scale`, the gated messages per edge row in-kernel.
+#include "e3_common.h"
+#include "cg_tables.h"
+
+#include <algorithm>
+#include <mutex>
+#include <utility>
+#include <vector>
+
+namespace e3 {
+
+#include "e3_tp_mfma_core.h"
+
+// ------------------------------------------------------------------------------------------------------------------
+// geometry of the operator, shared by host and device
+// ------------------------------------------------------------------------------------------------------------------
+template <int LMAX, int TT>
+struct MsgGeom {
+  static constexpr int H = 16 * TT;             // channels per degree
+  static constexpr int KS = (H + 31) / 32;      // K = 32 steps per degree and segment
+  static constexpr int D = H * (LMAX + 1) * (LMAX + 1);  // floats per feature row: [H x0e | H x1o | H x2e]
+  static constexpr int T(int l3) { return l3 == 0 ? TT * (1 + LMAX) : TT; }  // 16-channel output tiles (l3 = 0: scalars + gates)
+  static constexpr int col0(int l) { return H * l * l; }
+  static constexpr bool ok(int l1, int l2, int l3) {
+    return l1 >= 0 && l2 >= 0 && l3 >= 0 && l1 <= LMAX && l2 <= LMAX && l3 <= LMAX && ((l1 + l2 + l3) % 2 == 0) &&
+           l3 >= (l1 > l2 ? l1 - l2 : l2 - l1) && l3 <= l1 + l2;
+  }
+  // paths in kernel order: l1 outer, then l3, then l2.  Weight block (path, ks, t) = 64 lanes x (16 B hi + 16 B lo).
+  static constexpr int blk(int l1, int l2, int l3) {
+    int n = 0;
+    for (int a = 0; a <= LMAX; ++a)
+      for (int c = 0; c <= LMAX; ++c)
+        for (int b = 0; b <= LMAX; ++b) {
+          if (a == l1 && b == l2 && c == l3) return n;
+          if (ok(a, b, c)) n += KS * T(c);
+        }
+    return n;
+  }
+  static constexpr int nblk() { return blk(LMAX + 1, 0, 0); }
+  // dst pre-mix table U [N][UD]: per path [a][t][16 channels]
+  static constexpr int uoff(int l1, int l2, int l3) {
+    int n = 0;
+    for (int a = 0; a <= LMAX; ++a)
+      for (int c = 0; c <= LMAX; ++c)
+        for (int b = 0; b <= LMAX; ++b) {
+          if (a == l1 && b == l2 && c == l3) return n;
+          if (ok(a, b, c)) n += (2 * a + 1) * T(c) * 16;
+        }
+    return n;
+  }
+  static constexpr int UD = uoff(LMAX + 1, 0, 0);
+  // accumulator slots (one f32x4 per lane each): l3 = 0: t; l3 = 1: T0 + 3 t + c; l3 = 2: T0 + 3 TT + 5 t + c
+  static constexpr int slot0(int l3) { return l3 == 0 ? 0 : l3 == 1 ? T(0) : T(0) + 3 * TT; }
+  static constexpr int NS = T(0) + 3 * TT + (LMAX == 2 ? 5 * TT : 0);
+  // d-term weights: the distance channel of TP #1 couples through (0, l, l): [l][t][16]
+  static constexpr int wdoff(int l) { return l == 0 ? 0 : l == 1 ? T(0) * 16 : (T(0) + TT) * 16; }
+  static constexpr int WD = (T(0) + LMAX * TT) * 16;
+  // packed buffer (floats): [header 64 | norm1 NS*16 | norm2 NS*16 | Wd | pad to 64 | W src1 | W tp2 | W dst1]
+  static constexpr int o_norm1 = 64, o_norm2 = o_norm1 + NS * 16, o_wd = o_norm2 + NS * 16;
+  static constexpr int o_w = (o_wd + WD + 63) / 64 * 64;
+  static constexpr int blk_floats = 64 * 8;  // 64 lanes x (hi uint4 + lo uint4)
+  static constexpr int64_t total_floats = (int64_t)o_w + 3LL * nblk() * blk_floats;
+  static constexpr int lds_tab = 2 * NS * 16 + WD;  // floats of tables kept in LDS per workgroup
+  static constexpr int lds_wave = 16 * D;           // floats per wave: staged h[src] rows, later the parked messages
+};
+
+// k slot jj (0..7) of k group g inside a 32-channel K step  <->  channel: the accumulator layout of the previous product
+__host__ __device__ constexpr int kperm(int g, int jj) { return 16 * (jj >> 2) + 4 * g + (jj & 3); }
+
+// ------------------------------------------------------------------------------------------------------------------
+// weight packing
+// ------------------------------------------------------------------------------------------------------------------
+struct MsgPackDesc {  // one weight block
+  int role;           // 0: TP #1 src rows, 1: TP #2, 2: TP #1 dst rows (pre-mix)
+  int mat;            // output degree l3 = class matrix index
+  int rowbase;        // row of channel 0 of this K step in the class matrix
+  int nvalid;         // channels of this K step that exist (<= 32)
+  int M, colbase;     // matrix width, first output channel of the tile
+  int blk;            // block index inside the role
+};
+struct MsgPackArgs {
+  const float* w1[3];
+  const float* w2[3];
+  const float* n1[3];
+  const float* n2[3];
+  int64_t nw1[3], nw2[3];  // elements per class matrix
+  int rowd[3];             // row of the distance channel in class l's matrix (path (0, l, l)), TP #1
+  int M0, H, LMAX, TT, NS, WD, o_norm1, o_norm2, o_wd, o_w, nblk;
+};
+
+__global__ void msg_absmax_kernel(MsgPackArgs a, uint32_t* hdr) {
+  float m1 = 0.f, m2 = 0.f;
+  for (int c = 0; c < 3; ++c) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < a.nw1[c]; i += (int64_t)gridDim.x * blockDim.x)
+      m1 = fmaxf(m1, fabsf(a.w1[c][i]));
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < a.nw2[c]; i += (int64_t)gridDim.x * blockDim.x)
+      m2 = fmaxf(m2, fabsf(a.w2[c][i]));
+  }
+  for (int o = 32; o > 0; o >>= 1) { m1 = fmaxf(m1, __shfl_xor(m1, o)); m2 = fmaxf(m2, __shfl_xor(m2, o)); }
+  if ((threadIdx.x & 63) == 0) {
+    if (m1 > 0.f && m1 < INFINITY) atomicMax(hdr + 0, __builtin_bit_cast(uint32_t, m1));
+    if (m2 > 0.f && m2 < INFINITY) atomicMax(hdr + 3, __builtin_bit_cast(uint32_t, m2));
+  }
+}
+
+__global__ void msg_pack_kernel(MsgPackArgs a, const MsgPackDesc* desc, int ndesc, float* packed) {
+  const uint32_t* hb = reinterpret_cast<const uint32_t*>(packed);
+  const float sw1 = pow2_scale_from_bits(hb[0], 13), sw2 = pow2_scale_from_bits(hb[3], 13);
+  for (int r = blockIdx.x; r < ndesc; r += gridDim.x) {
+    const MsgPackDesc q = desc[r];
+    const float* W = q.role == 1 ? a.w2[q.mat] : a.w1[q.mat];
+    const float sw = q.role == 1 ? sw2 : sw1;
+    uint16_t* dst = reinterpret_cast<uint16_t*>(packed + a.o_w + ((size_t)q.role * a.nblk + q.blk) * 512);
+    for (int i = threadIdx.x; i < 512; i += blockDim.x) {
+      const int lane = i >> 3, jj = i & 7, ch = lane & 15, g = lane >> 4;
+      const int k = kperm(g, jj);
+      float v = 0.f;
+      if (k < q.nvalid && q.colbase + ch < q.M) v = W[(int64_t)(q.rowbase + k) * q.M + q.colbase + ch] * sw;
+      const _Float16 hi = (_Float16)v;
+      const _Float16 lo = (_Float16)(v - (float)hi);
+      dst[lane * 8 + jj] = __builtin_bit_cast(uint16_t, hi);
+      dst[512 + lane * 8 + jj] = __builtin_bit_cast(uint16_t, lo);
+    }
+  }
+  if (blockIdx.x == 0) {
+    // norm tables in accumulator order, already divided by the weight scale; d-term weights scaled like the others
+    for (int i = threadIdx.x; i < a.NS * 16; i += blockDim.x) {
+      const int s = i >> 4, ch = i & 15;
+      const int T0 = a.TT * (1 + a.LMAX);
+      int l3, t, c;
+      if (s < T0) { l3 = 0; t = s; c = 0; }
+      else if (s < T0 + 3 * a.TT) { l3 = 1; t = (s - T0) / 3; c = (s - T0) % 3; }
+      else { l3 = 2; t = (s - T0 - 3 * a.TT) / 5; c = (s - T0 - 3 * a.TT) % 5; }
+      const int idx = (16 * t + ch) * (2 * l3 + 1) + c;
+      packed[a.o_norm1 + i] = (a.n1[l3] ? a.n1[l3][idx] : 1.0f) / sw1;
+      packed[a.o_norm2 + i] = (a.n2[l3] ? a.n2[l3][idx] : 1.0f) / sw2;
+    }
+    for (int i = threadIdx.x; i < a.WD; i += blockDim.x) {
+      const int T0 = a.TT * (1 + a.LMAX);
+      int l, rem;
+      if (i < T0 * 16) { l = 0; rem = i; }
+      else if (i < (T0 + a.TT) * 16) { l = 1; rem = i - T0 * 16; }
+      else { l = 2; rem = i - (T0 + a.TT) * 16; }
+      const int M = l == 0 ? a.M0 : a.H;
+      packed[a.o_wd + i] = a.w1[l][(int64_t)a.rowd[l] * M + rem] * sw1;
+    }
+    if (threadIdx.x == 0) {
+      packed[1] = sw1; packed[2] = 1.0f / sw1;
+      packed[4] = sw2; packed[5] = 1.0f / sw2;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// device building blocks
+// ------------------------------------------------------------------------------------------------------------------
+template <int L1, int L2, int L3>
+__device__ __forceinline__ void make_z(const float (&y)[9], float (&z)[2 * L1 + 1][2 * L3 + 1]) {
+  using C = CG<L1, L2, L3>;
+#pragma unroll
+  for (int a = 0; a < 2 * L1 + 1; ++a)
+#pragma unroll
+    for (int c = 0; c < 2 * L3 + 1; ++c) {
+      float s = 0.f;
+      bool have = false;
+#pragma unroll
+      for (int b = 0; b < 2 * L2 + 1; ++b)
+        if (C::v[a][b][c] != 0.0) {
+          s = have ? __builtin_fmaf((float)C::v[a][b][c], y[L2 * L2 + b], s) : (float)C::v[a][b][c] * y[L2 * L2 + b];
+          have = true;
+        }
+      z[a][c] = s;
+    }
+}
+template <int L1, int L2, int L3>
+__host__ __device__ constexpr bool z_nonzero(int a, int c) {
+  for (int b = 0; b < 2 * L2 + 1; ++b)
+    if (CG<L1, L2, L3>::v[a][b][c] != 0.0) return true;
+  return false;
+}
+
+// three f16 MFMAs = one fp32-grade product group
+__device__ __forceinline__ f32x4 mma3(const uint4 ah, const uint4 al, const uint4 bh, const uint4 bl, f32x4 c) {
+  c = mfma16h(__builtin_bit_cast(f16x8, ah), __builtin_bit_cast(f16x8, bh), c);
+  c = mfma16h(__builtin_bit_cast(f16x8, ah), __builtin_bit_cast(f16x8, bl), c);
+  c = mfma16h(__builtin_bit_cast(f16x8, al), __builtin_bit_cast(f16x8, bh), c);
+  return c;
+}
+
+__device__ __forceinline__ void split8(const float (&f)[8], uint4& bh, uint4& bl) {
+  uint32_t ph[4], pl[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) split2_f16(f[2 * q], f[2 * q + 1], ph[q], pl[q]);
+  bh = uint4{ph[0], ph[1], ph[2], ph[3]};
+  bl = uint4{pl[0], pl[1], pl[2], pl[3]};
+}
+
+// Everything one tensor product needs besides its inputs.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+struct TpCtx {
+  __amdgpu_buffer_rsrc_t w;  // buffer descriptor over ALL weight blocks (wave-uniform, 4 SGPRs)
+  uint32_t wrole;       // byte offset of this role's first block; block b at wrole + b * 2048 (1 KiB hi then 1 KiB lo)
+  uint32_t woff;        // this lane's byte offset inside a block half: lane * 16
+  const float* ud;      // FIRST: this lane's row of the dst pre-mix table (+ 4 g), else nullptr
+  const float* wd;      // FIRST: d-term weights in LDS (+ 4 g)
+  float dsc;            // FIRST: distance * xs
+};
+
+// A operand of one weight block: buffer load = descriptor (SGPRs) + scalar block offset + this lane's 32-bit offset, so
+// the ~70 block addresses of a product cost no vector registers and no 64-bit address arithmetic
+__device__ __forceinline__ void load_w(const TpCtx& cx, const int blk, uint4& hi, uint4& lo) {
+  const uint32_t so = cx.wrole + (uint32_t)blk * 2048u;
+  const u32x4 h = __builtin_amdgcn_raw_buffer_load_b128(cx.w, cx.woff, so, 0);
+  const u32x4 l = __builtin_amdgcn_raw_buffer_load_b128(cx.w, cx.woff + 1024u, so, 0);
+  hi = uint4{h[0], h[1], h[2], h[3]};
+  lo = uint4{l[0], l[1], l[2], l[3]};
+}
+
+// One tensor product on the lane's 16-edge tile.  XLOAD(l1tag, ks, x[8][D1]) delivers the (scaled) fp32 inputs of this
+// lane: x[jj][a] = channel 32 ks + kperm(g, jj), component a.  acc0 / acc1 / acc2: output tiles per degree.
+// Live registers are bounded by construction: per input degree the fp32 inputs exist only until the feature-first path
+// has run and the (hi, lo) halves are built; mix-first paths hold ONE temporary tile group u[a] at a time.
+template <int LMAX, int TT, bool FIRST, class XLOAD>
+__device__ __forceinline__ void tp_core(const TpCtx& cx, const float (&y)[9], XLOAD&& xload,
+                                        f32x4 (&acc0)[MsgGeom<LMAX, TT>::T(0)], f32x4 (&acc1)[TT][3],
+                                        f32x4 (&acc2)[LMAX == 2 ? TT : 1][5]) {
+  using G = MsgGeom<LMAX, TT>;
+  constexpr int KS = G::KS;
+  auto per_l1 = [&](auto l1tag) {
+    constexpr int L1 = decltype(l1tag)::value;
+    constexpr int D1 = 2 * L1 + 1;
+    uint4 xh[KS][D1], xl[KS][D1];
+    {
+      float x[KS][8][D1];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) xload(l1tag, ks, x[ks]);
+      if constexpr (L1 > 0 && G::ok(L1, L1, 0)) {
+        // feature first (into the scalar outputs): f[k] = sum_a z[a] x[k][a], one product group per tile
+        constexpr int T = G::T(0), B0 = G::blk(L1, L1, 0), U0 = G::uoff(L1, L1, 0);
+        float z[D1][1];
+        make_z<L1, L1, 0>(y, z);
+        uint4 fh[KS], fl[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          float f[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            float s = z[0][0] * x[ks][i][0];
+#pragma unroll
+            for (int a = 1; a < D1; ++a) s = __builtin_fmaf(z[a][0], x[ks][i][a], s);
+            f[i] = s;
+          }
+          split8(f, fh[ks], fl[ks]);
+        }
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            uint4 ah, al;
+            load_w(cx, B0 + ks * T + t, ah, al);
+            acc0[t] = mma3(ah, al, fh[ks], fl[ks], acc0[t]);
+          }
+          if constexpr (FIRST) {  // dst half: fold of the per-node pre-mix
+#pragma unroll
+            for (int a = 0; a < D1; ++a) {
+              const f32x4 u = *reinterpret_cast<const f32x4*>(cx.ud + U0 + (a * T + t) * 16);
+              acc0[t] += u * z[a][0];
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int a = 0; a < D1; ++a) {
+          float f[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) f[i] = x[ks][i][a];
+          split8(f, xh[ks][a], xl[ks][a]);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    auto per_path = [&](auto l2tag, auto l3tag) {
+      constexpr int L2 = decltype(l2tag)::value, L3 = decltype(l3tag)::value;
+      if constexpr (G::ok(L1, L2, L3) && !(L3 == 0 && L1 > 0)) {
+        constexpr int D3 = 2 * L3 + 1, T = G::T(L3);
+        constexpr int B0 = G::blk(L1, L2, L3), U0 = G::uoff(L1, L2, L3);
+        float z[D1][D3];
+        make_z<L1, L2, L3>(y, z);
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          __builtin_amdgcn_sched_barrier(0);
+          f32x4 u[D1];
+#pragma unroll
+          for (int a = 0; a < D1; ++a) {
+            if constexpr (FIRST)
+              u[a] = *reinterpret_cast<const f32x4*>(cx.ud + U0 + (a * T + t) * 16);
+            else
+              u[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+          if constexpr (FIRST && L1 == 0) {
+            const f32x4 wdv = *reinterpret_cast<const f32x4*>(cx.wd + G::wdoff(L3) + t * 16);
+            u[0] += wdv * cx.dsc;
+          }
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            uint4 ah, al;
+            load_w(cx, B0 + ks * T + t, ah, al);
+#pragma unroll
+            for (int a = 0; a < D1; ++a) u[a] = mma3(ah, al, xh[ks][a], xl[ks][a], u[a]);
+          }
+#pragma unroll
+          for (int c = 0; c < D3; ++c)
+#pragma unroll
+            for (int a = 0; a < D1; ++a)
+              if (z_nonzero<L1, L2, L3>(a, c)) {
+                if constexpr (L3 == 0) acc0[t] += u[a] * z[a][c];
+                else if constexpr (L3 == 1) acc1[t][c] += u[a] * z[a][c];
+                else acc2[t][c] += u[a] * z[a][c];
+              }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    per_path(I0{}, I0{}); per_path(I1{}, I0{}); per_path(I2{}, I0{});
+    per_path(I0{}, I1{}); per_path(I1{}, I1{}); per_path(I2{}, I1{});
+    per_path(I0{}, I2{}); per_path(I1{}, I2{}); per_path(I2{}, I2{});
+  };
+  per_l1(std::integral_constant<int, 0>{});
+  per_l1(std::integral_constant<int, 1>{});
+  if constexpr (LMAX == 2) per_l1(std::integral_constant<int, 2>{});
+}
+
+// real "component" spherical harmonics of the edge vector (same expressions as edge_geometry_l2_kernel, e3_edge_ops.hip)
+__device__ __forceinline__ void edge_sh(const float4 ps, const float4 pd, float (&y)[9], float& dist) {
+  const float rx = ps.x - pd.x, ry = ps.y - pd.y, rz = ps.z - pd.z;
+  const float d = sqrtf(rx * rx + ry * ry + rz * rz);
+  const float inv = d > 0.f ? 1.0f / d : 0.f;
+  const float x = rx * inv, yy = ry * inv, z = rz * inv;
+  constexpr float s3 = 1.7320508075688772f, s5 = 2.2360679774997896f;
+  y[0] = 1.0f;
+  y[1] = s3 * x; y[2] = s3 * yy; y[3] = s3 * z;
+  y[4] = s5 * s3 * x * yy;
+  y[5] = s5 * s3 * yy * z;
+  y[6] = s5 * 0.5f * (2.f * z * z - x * x - yy * yy);
+  y[7] = s5 * s3 * z * x;
+  y[8] = s5 * 0.5f * s3 * (x * x - yy * yy);
+  dist = d;
+}
+// l <= 1 variant: identical to edge_geometry_kernel (s = sqrt3 / d folded first)
+__device__ __forceinline__ void edge_sh1(const float4 ps, const float4 pd, float (&y)[9], float& dist) {
+  const float rx = ps.x - pd.x, ry = ps.y - pd.y, rz = ps.z - pd.z;
+  const float d = sqrtf(rx * rx + ry * ry + rz * rz);
+  const float s = d > 0.f ? 1.7320508075688772f / d : 0.f;
+  y[0] = 1.0f; y[1] = s * rx; y[2] = s * ry; y[3] = s * rz;
+#pragma unroll
+  for (int q = 4; q < 9; ++q) y[q] = 0.f;
+  dist = d;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// pre-mix: U[n] = (W_dst * sw) (h[n] * xs) for every path of TP #1, in the layout the edge kernel reads as accumulator
+// initial values.  One wave per 16 nodes; inputs straight from global memory (each lane reads its own k slots).
+// ------------------------------------------------------------------------------------------------------------------
+template <int LMAX, int TT>
+__global__ __launch_bounds__(256) void msg_premix_kernel(const float* __restrict__ h, int64_t ldh, int64_t N,
+                                                         const float* __restrict__ packed,
+                                                         const float* __restrict__ in_scale, float* __restrict__ U) {
+  using G = MsgGeom<LMAX, TT>;
+  const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+  const int64_t wave0 = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const float xs = in_scale ? in_scale[0] : 1.0f;
+  TpCtx cx;
+  cx.w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(packed + G::o_w), 0, 3 * G::nblk() * 2048, 0x00020000);
+  cx.wrole = 2 * G::nblk() * 2048;  // role 2
+  cx.woff = lane * 16; cx.ud = nullptr; cx.wd = nullptr; cx.dsc = 0.f;
+  const int64_t ntiles = (N + 15) / 16;
+  for (int64_t tile = wave0; tile < ntiles; tile += nw) {
+    const int64_t n = tile * 16 + j;
+    const bool ok = n < N;
+    const float* row = h + (ok ? n : N - 1) * ldh;
+    float* urow = U + (ok ? n : N - 1) * (int64_t)G::UD + 4 * g;
+    auto per_l1 = [&](auto l1tag) {
+      constexpr int L1 = decltype(l1tag)::value, D1 = 2 * L1 + 1;
+      uint4 xh[G::KS][D1], xl[G::KS][D1];
+#pragma unroll
+      for (int ks = 0; ks < G::KS; ++ks) {
+        float x[8][D1];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          const int ch0 = 32 * ks + 16 * p + 4 * g;
+          if (16 * (2 * ks + p) < G::H) {
+            const float4* src = reinterpret_cast<const float4*>(row + G::col0(L1) + ch0 * D1);
+            float q[4 * D1];
+#pragma unroll
+            for (int u = 0; u < D1; ++u) {
+              const float4 v = src[u];
+              q[4 * u] = v.x; q[4 * u + 1] = v.y; q[4 * u + 2] = v.z; q[4 * u + 3] = v.w;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+              for (int a = 0; a < D1; ++a) x[4 * p + r][a] = q[r * D1 + a] * xs;
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+              for (int a = 0; a < D1; ++a) x[4 * p + r][a] = 0.f;
+          }
+        }
+#pragma unroll
+        for (int a = 0; a < D1; ++a) {
+          float f[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) f[i] = x[i][a];
+          split8(f, xh[ks][a], xl[ks][a]);
+        }
+      }
+      auto per_path = [&](auto l2tag, auto l3tag) {
+        constexpr int L2 = decltype(l2tag)::value, L3 = decltype(l3tag)::value;
+        if constexpr (G::ok(L1, L2, L3)) {
+          constexpr int T = G::T(L3), B0 = G::blk(L1, L2, L3), U0 = G::uoff(L1, L2, L3);
+#pragma unroll
+          for (int t = 0; t < T; ++t) {
+            f32x4 u[D1];
+#pragma unroll
+            for (int a = 0; a < D1; ++a) u[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < G::KS; ++ks) {
+              uint4 ah, al;
+              load_w(cx, B0 + ks * T + t, ah, al);
+#pragma unroll
+              for (int a = 0; a < D1; ++a) u[a] = mma3(ah, al, xh[ks][a], xl[ks][a], u[a]);
+            }
+            if (ok) {
+#pragma unroll
+              for (int a = 0; a < D1; ++a) *reinterpret_cast<f32x4*>(urow + U0 + (a * T + t) * 16) = u[a];
+            }
+          }
+        }
+      };
+      using I0 = std::integral_constant<int, 0>;
+      using I1 = std::integral_constant<int, 1>;
+      using I2 = std::integral_constant<int, 2>;
+      per_path(I0{}, I0{}); per_path(I1{}, I0{}); per_path(I2{}, I0{});
+      per_path(I0{}, I1{}); per_path(I1{}, I1{}); per_path(I2{}, I1{});
+      per_path(I0{}, I2{}); per_path(I1{}, I2{}); per_path(I2{}, I2{});
+    };
+    per_l1(std::integral_constant<int, 0>{});
+    per_l1(std::integral_constant<int, 1>{});
+    if constexpr (LMAX == 2) per_l1(std::integral_constant<int, 2>{});
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// the edge kernel
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int msg_waves_per_simd(int lmax, int tt) { return (lmax == 2 ? 44 : 20) * tt <= 96 ? 2 : 1; }
+
+template <int LMAX, int TT>
+__global__ __launch_bounds__(256, msg_waves_per_simd(LMAX, TT)) void msg_fused_kernel(
+    const float* __restrict__ h, int64_t ldh, const float4* __restrict__ pos4, const int32_t* __restrict__ src,
+    const int32_t* __restrict__ dst, int64_t E, const float* __restrict__ packed, const float* __restrict__ U,
+    const float* __restrict__ in_scale, float* __restrict__ out, int64_t ldo, int64_t tiles_per_wg, int blk) {
+  using G = MsgGeom<LMAX, TT>;
+  constexpr int H = G::H, D = G::D, T0 = G::T(0), NS = G::NS;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  float* lds = reinterpret_cast<float*>(smem_raw);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, g = lane >> 4;
+
+  // workgroup tables: norm1 (x 1/xs), norm2, d-term weights
+  float* n1tab = lds;
+  float* n2tab = n1tab + NS * 16;
+  float* wdtab = n2tab + NS * 16;
+  float* wbuf = wdtab + G::WD + (size_t)wave * G::lds_wave;
+  const float xs = in_scale ? in_scale[0] : 1.0f, ixs = in_scale ? in_scale[1] : 1.0f;
+  for (int i = tid; i < NS * 16; i += blockDim.x) {
+    n1tab[i] = packed[G::o_norm1 + i] * ixs;
+    n2tab[i] = packed[G::o_norm2 + i];
+  }
+  for (int i = tid; i < G::WD; i += blockDim.x) wdtab[i] = packed[G::o_wd + i];
+  __syncthreads();
+
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(packed + G::o_w), 0, 3 * G::nblk() * 2048, 0x00020000);
+
+  // workgroup -> contiguous tile range, XCD-aware: workgroups b, b + 8, b + 16, ... share an XCD (round-robin dispatch),
+  // so the XCD with label b & 7 gets one contiguous eighth of the tiles and its L2 sees one spatial range of h / U
+  const int64_t ntiles = (E + 15) / 16;
+  const int nwg = gridDim.x;
+  const int per_xcd = nwg >> 3;  // grid is a multiple of 8
+  const int64_t pos = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  const int64_t wg_lo = pos * tiles_per_wg;
+  int64_t wg_hi = wg_lo + tiles_per_wg;
+  if (wg_hi > ntiles) wg_hi = ntiles;
+
+  // running segment sum across consecutive tiles of this wave: node id (wave uniform) + one column per lane and group
+  constexpr int NG1 = (3 * H + 63) / 64, NG2 = (5 * H + 63) / 64;
+  int cur = -1;
+  float carry0 = 0.f, carry1[NG1], carry2[LMAX == 2 ? NG2 : 1];
+#pragma unroll
+  for (int q = 0; q < NG1; ++q) carry1[q] = 0.f;
+#pragma unroll
+  for (int q = 0; q < (LMAX == 2 ? NG2 : 1); ++q) carry2[q] = 0.f;
+  auto flush = [&]() {
+    if (cur >= 0) {
+      float* o = out + (int64_t)cur * ldo;
+      if (lane < H) __builtin_amdgcn_global_atomic_fadd_f32(o + lane, carry0);
+#pragma unroll
+      for (int q = 0; q < NG1; ++q)
+        if (64 * q + lane < 3 * H) __builtin_amdgcn_global_atomic_fadd_f32(o + H + 64 * q + lane, carry1[q]);
+      if constexpr (LMAX == 2) {
+#pragma unroll
+        for (int q = 0; q < NG2; ++q)
+          if (64 * q + lane < 5 * H) __builtin_amdgcn_global_atomic_fadd_f32(o + 4 * H + 64 * q + lane, carry2[q]);
+      }
+    }
+    carry0 = 0.f;
+#pragma unroll
+    for (int q = 0; q < NG1; ++q) carry1[q] = 0.f;
+#pragma unroll
+    for (int q = 0; q < (LMAX == 2 ? NG2 : 1); ++q) carry2[q] = 0.f;
+    cur = -1;
+  };
+
+  for (int64_t b0 = wg_lo + (int64_t)wave * blk; b0 < wg_hi; b0 += 4 * (int64_t)blk) {
+    const int64_t b1 = b0 + blk < wg_hi ? b0 + blk : wg_hi;
+    for (int64_t tile = b0; tile < b1; ++tile) {
+      const int64_t row0 = tile * 16;
+      const int nrows = (int)((E - row0) < 16 ? (E - row0) : 16);
+      // per-tile opaque copies of loop-invariant addresses: without them LICM hoists ~50 table reads (200 registers) and
+      // the block addresses out of the tile loop and spills them
+      uint32_t woff = lane * 16;
+      const float *n1p = n1tab, *n2p = n2tab, *wdp = wdtab;
+      asm volatile("" : "+v"(woff), "+v"(n1p), "+v"(n2p), "+v"(wdp));
+      const int64_t e = row0 + (j < nrows ? j : nrows - 1);
+      const int sid = src[e], did = dst[e];
+      const int sd = j < nrows ? did : -1;
+
+      // ---- stage the 16 h[src] rows by 16-byte LDS-DMA (the per-lane source address is the gather).  LDS image per wave:
+      //      l_max 2: region A [row][1o | 2e] (2 H units of 16 bytes per row) then region B [row][0e] (H / 4 units);
+      //      l_max 1: one region [row][0e | 1o] (H units).  Unit counts are powers of two, so a DMA instruction covers whole
+      //      rows (row id by v_readlane: scalar address math) or 2^k rows (one shuffle), and no lane divides anything.
+      // (the previous tile's LDS reads must have returned before the copies may land)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      wave_sync_lds();
+      {
+        auto stage_region = [&](auto utag, auto otag, float* dstf) {
+          constexpr int UNITS = decltype(utag)::value, SRCOFF = decltype(otag)::value;  // units per row, first source float
+          if constexpr (UNITS >= 64) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int rid = __builtin_amdgcn_readlane(sid, r);
+              const float* rowp = h + (int64_t)rid * ldh + SRCOFF;
+#pragma unroll
+              for (int k = 0; k < UNITS / 64; ++k)
+                __builtin_amdgcn_global_load_lds((glb_void_t*)(rowp + (k * 64 + lane) * 4),
+                                                 (lds_void_t*)(dstf + (r * UNITS + k * 64) * 4), 16, 0, 0);
+            }
+          } else {
+            constexpr int RPI = 64 / UNITS;  // rows per instruction
+            const int u = lane & (UNITS - 1), rl = lane / UNITS;
+#pragma unroll
+            for (int it = 0; it < 16 / RPI; ++it) {
+              const int rid = __shfl(sid, it * RPI + rl);
+              __builtin_amdgcn_global_load_lds((glb_void_t*)(h + (int64_t)rid * ldh + SRCOFF + u * 4),
+                                               (lds_void_t*)(dstf + it * 256), 16, 0, 0);
+            }
+          }
+        };
+        if constexpr (LMAX == 2) {
+          stage_region(std::integral_constant<int, 2 * H>{}, std::integral_constant<int, H>{}, wbuf);
+          stage_region(std::integral_constant<int, H / 4>{}, std::integral_constant<int, 0>{}, wbuf + 16 * 8 * H);
+        } else {
+          stage_region(std::integral_constant<int, H>{}, std::integral_constant<int, 0>{}, wbuf);
+        }
+      }
+      // ---- geometry while the copies fly ----
+      float y[9], dist;
+      {
+        const float4 ps = pos4[sid], pd = pos4[did];
+        if constexpr (LMAX == 2) edge_sh(ps, pd, y, dist); else edge_sh1(ps, pd, y, dist);
+      }
+      f32x4 a0[T0], a1[TT][3], a2[LMAX == 2 ? TT : 1][5];
+      const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < T0; ++t) a0[t] = zero4;
+#pragma unroll
+      for (int t = 0; t < TT; ++t)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) a1[t][c] = zero4;
+#pragma unroll
+      for (int t = 0; t < (LMAX == 2 ? TT : 1); ++t)
+#pragma unroll
+        for (int c = 0; c < 5; ++c) a2[t][c] = zero4;
+
+      wait_vm0();
+      wave_sync_lds();
+
+      // ---- tensor product #1: x from the staged rows, dst half as accumulator initial values ----
+      {
+        TpCtx cx;
+        cx.w = wrsrc;
+        cx.wrole = 0;
+        cx.woff = woff;
+        cx.ud = U + (int64_t)did * G::UD + 4 * g;
+        cx.wd = wdp + 4 * g;
+        cx.dsc = dist * xs;
+        auto xload = [&](auto l1tag, int ks, auto& x) {
+          constexpr int L1 = decltype(l1tag)::value, D1 = 2 * L1 + 1;
+          // first float of degree L1 in this lane's staged row (see the LDS image above)
+          const float* xrow = LMAX == 2 ? (L1 == 0 ? wbuf + 16 * 8 * H + j * H : wbuf + j * 8 * H + (L1 == 1 ? 0 : 3 * H))
+                                        : wbuf + j * 4 * H + (L1 == 0 ? 0 : H);
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+            if (16 * (2 * ks + p) < H) {
+              const float4* sp = reinterpret_cast<const float4*>(xrow + (32 * ks + 16 * p + 4 * g) * D1);
+              float q[4 * D1];
+#pragma unroll
+              for (int u = 0; u < D1; ++u) {
+                const float4 v = sp[u];
+                q[4 * u] = v.x; q[4 * u + 1] = v.y; q[4 * u + 2] = v.z; q[4 * u + 3] = v.w;
+              }
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int a = 0; a < D1; ++a) x[4 * p + r][a] = q[r * D1 + a] * xs;
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int a = 0; a < D1; ++a) x[4 * p + r][a] = 0.f;
+            }
+          }
+        };
+        tp_core<LMAX, TT, true>(cx, y, xload, a0, a1, a2);
+      }
+
+      // ---- gate #1; the messages stay in accumulator layout = the B-operand layout of product #2 ----
+      // (norm1 already carries 1 / (sw1 xs)); row scale for the fp16 split: max |m| of the lane's edge -> 2^10
+      float amax = 0.f;
+      {
+        const f32x4* nt = reinterpret_cast<const f32x4*>(n1p) + g;  // slot s at nt[4 s]
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+          f32x4 s = a0[t] * nt[4 * t];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { s[r] = s[r] * sigmoid_(s[r]); amax = fmaxf(amax, fabsf(s[r])); }
+          a0[t] = s;
+        }
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+          f32x4 gt = a0[TT + t] * nt[4 * (TT + t)];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) gt[r] = sigmoid_(gt[r]);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const f32x4 v = a1[t][c] * nt[4 * (G::slot0(1) + 3 * t + c)] * gt;
+            a1[t][c] = v;
+            amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+          }
+        }
+        if constexpr (LMAX == 2) {
+#pragma unroll
+          for (int t = 0; t < TT; ++t) {
+            f32x4 gt = a0[2 * TT + t] * nt[4 * (2 * TT + t)];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gt[r] = sigmoid_(gt[r]);
+#pragma unroll
+            for (int c = 0; c < 5; ++c) {
+              const f32x4 v = a2[t][c] * nt[4 * (G::slot0(2) + 5 * t + c)] * gt;
+              a2[t][c] = v;
+              amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+            }
+          }
+        }
+      }
+      amax = fmaxf(amax, __shfl_xor(amax, 16));
+      amax = fmaxf(amax, __shfl_xor(amax, 32));
+      const float srow = pow2_scale_from_bits(__builtin_bit_cast(uint32_t, amax), 10);
+      const float isrow = 1.0f / srow;
+
+      // ---- park the (scaled) messages: slot q of lane l at wbuf[(q * 64 + l) * 4] ----
+      wave_sync_lds();
+      {
+        f32x4* pk = reinterpret_cast<f32x4*>(wbuf) + lane;
+#pragma unroll
+        for (int t = 0; t < TT; ++t) pk[64 * t] = a0[t] * srow;
+#pragma unroll
+        for (int t = 0; t < TT; ++t)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) pk[64 * (TT + 3 * t + c)] = a1[t][c] * srow;
+        if constexpr (LMAX == 2) {
+#pragma unroll
+          for (int t = 0; t < TT; ++t)
+#pragma unroll
+            for (int c = 0; c < 5; ++c) pk[64 * (4 * TT + 5 * t + c)] = a2[t][c] * srow;
+        }
+      }
+      wave_sync_lds();
+
+      // ---- tensor product #2 ----
+#pragma unroll
+      for (int t = 0; t < T0; ++t) a0[t] = zero4;
+#pragma unroll
+      for (int t = 0; t < TT; ++t)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) a1[t][c] = zero4;
+#pragma unroll
+      for (int t = 0; t < (LMAX == 2 ? TT : 1); ++t)
+#pragma unroll
+        for (int c = 0; c < 5; ++c) a2[t][c] = zero4;
+      {
+        TpCtx cx;
+        cx.w = wrsrc; cx.wrole = G::nblk() * 2048; cx.woff = woff; cx.ud = nullptr; cx.wd = nullptr; cx.dsc = 0.f;
+        const f32x4* pk = reinterpret_cast<const f32x4*>(wbuf) + lane;
+        auto xload = [&](auto l1tag, int ks, auto& x) {
+          constexpr int L1 = decltype(l1tag)::value, D1 = 2 * L1 + 1;
+          constexpr int S0 = L1 == 0 ? 0 : L1 == 1 ? TT : 4 * TT;  // first parked slot of degree L1
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+            const int t = 2 * ks + p;
+#pragma unroll
+            for (int a = 0; a < D1; ++a) {
+              f32x4 v = zero4;
+              if (t < TT) v = pk[64 * (S0 + D1 * t + a)];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) x[4 * p + r][a] = v[r];
+            }
+          }
+        };
+        tp_core<LMAX, TT, false>(cx, y, xload, a0, a1, a2);
+      }
+
+      // ---- gate #2 and segment sum: per degree block, transpose through LDS ([row][comp][channel]), then lane = output
+      //      column walks the 16 rows and adds runs of equal dst; the last run is carried into the next tile ----
+      const f32x4* nt2 = reinterpret_cast<const f32x4*>(n2p) + g;
+      int cur_end = cur;
+      auto block = [&](auto dtag, auto val, float* carry, const int colbase) {
+        constexpr int Dc = decltype(dtag)::value;  // components of this degree
+        constexpr int RS = Dc * H + 1;             // LDS row stride (floats), odd: [row][column in output order]
+        constexpr int NG = (Dc * H + 63) / 64;
+        wave_sync_lds();
+        float* wp = wbuf + j * RS + 4 * g * Dc;
+#pragma unroll
+        for (int t = 0; t < TT; ++t)
+#pragma unroll
+          for (int c = 0; c < Dc; ++c) {
+            const f32x4 v = val(t, c);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) wp[(16 * t + r) * Dc + c] = v[r];
+          }
+        wave_sync_lds();
+#pragma unroll
+        for (int q = 0; q < NG; ++q) {
+          const int col = 64 * q + lane;
+          const bool cok = col < Dc * H;
+          const float* sp = wbuf + (cok ? col : 0);
+          float acc = carry[q];
+          int run = cur;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int dn = __builtin_amdgcn_readlane(sd, r);
+            if (dn != run && dn >= 0) {
+              if (run >= 0 && cok) __builtin_amdgcn_global_atomic_fadd_f32(out + (int64_t)run * ldo + colbase + col, acc);
+              acc = 0.f;
+              run = dn;
+            }
+            if (dn >= 0) acc += sp[r * RS];
+          }
+          carry[q] = acc;
+          cur_end = run;
+        }
+      };
+      using I1 = std::integral_constant<int, 1>;
+      using I3 = std::integral_constant<int, 3>;
+      using I5 = std::integral_constant<int, 5>;
+      block(I1{}, [&](int t, int) {
+        f32x4 s = a0[t] * nt2[4 * t] * isrow;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[r] = s[r] * sigmoid_(s[r]);
+        return s;
+      }, &carry0, 0);
+      {
+        f32x4 gt[TT];
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+          gt[t] = a0[TT + t] * nt2[4 * (TT + t)] * isrow;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) gt[t][r] = sigmoid_(gt[t][r]);
+        }
+        block(I3{}, [&](int t, int c) { return a1[t][c] * nt2[4 * (G::slot0(1) + 3 * t + c)] * isrow * gt[t]; }, carry1, H);
+      }
+      if constexpr (LMAX == 2) {
+        f32x4 gt[TT];
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+          gt[t] = a0[2 * TT + t] * nt2[4 * (2 * TT + t)] * isrow;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) gt[t][r] = sigmoid_(gt[t][r]);
+        }
+        block(I5{}, [&](int t, int c) { return a2[t][c] * nt2[4 * (G::slot0(2) + 5 * t + c)] * isrow * gt[t]; }, carry2, 4 * H);
+      }
+      cur = cur_end;
+    }
+    flush();  // the wave's next tile is not the successor of this one
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// host
+// ------------------------------------------------------------------------------------------------------------------
+struct MsgKernels {
+  int lmax, tt;
+  const void* fused;
+  const void* premix;
+  int64_t total_floats;
+  int UD, D, lds_tab, lds_wave, nblk, NS, WD, o_norm1, o_norm2, o_wd, o_w, waves_per_simd;
+};
+template <int LMAX, int TT>
+static MsgKernels make_entry() {
+  using G = MsgGeom<LMAX, TT>;
+  return {LMAX, TT, (const void*)msg_fused_kernel<LMAX, TT>, (const void*)msg_premix_kernel<LMAX, TT>, G::total_floats,
+          G::UD, G::D, G::lds_tab, G::lds_wave, G::nblk(), G::NS, G::WD, G::o_norm1, G::o_norm2, G::o_wd, G::o_w,
+          msg_waves_per_simd(LMAX, TT)};
+}
+static const std::vector<MsgKernels>& msg_kernels() {
+  static const std::vector<MsgKernels> k = {make_entry<2, 2>(), make_entry<1, 2>(), make_entry<2, 1>(), make_entry<1, 1>(),
+                                            make_entry<2, 4>(), make_entry<1, 4>()};
+  return k;
+}
+
+}  // namespace e3
+
+using namespace e3;
+
+struct e3_msg_plan {
+  int lmax, H;
+  const MsgKernels* k;
+  std::vector<MsgPackDesc> desc;
+  int rowd[3];
+  int K1[3], K2[3], M[3];
+  MsgPackDesc* d_desc = nullptr;
+  int device = -1;
+  std::mutex mu;
+};
+
+static int msg_ensure_device(e3_msg_plan* P) {
+  std::lock_guard<std::mutex> lock(P->mu);
+  int cur = -1;
+  if (hipGetDevice(&cur) != hipSuccess) return E3_ERR_NO_DEVICE;
+  if (P->d_desc) return cur == P->device ? E3_OK : E3_ERR_INVALID_ARG;
+  MsgPackDesc* d = nullptr;
+  E3_HIP_CHECK(hipMalloc((void**)&d, P->desc.size() * sizeof(MsgPackDesc)));
+  if (hipMemcpy(d, P->desc.data(), P->desc.size() * sizeof(MsgPackDesc), hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipFree(d);
+    return E3_ERR_HIP;
+  }
+  const size_t lds = (size_t)(P->k->lds_tab + 4 * P->k->lds_wave) * 4;
+  if (hipFuncSetAttribute(P->k->fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    (void)hipFree(d);
+    return E3_ERR_HIP;
+  }
+  P->device = cur;
+  P->d_desc = d;
+  return E3_OK;
+}
+
+extern "C" {
+
+int e3_msg_plan_create(int lmax, int hidden, e3_msg_plan** plan_out) {
+  if (!plan_out || lmax < 1 || lmax > 2) return E3_ERR_INVALID_ARG;
+  const MsgKernels* k = nullptr;
+  for (auto& e : msg_kernels())
+    if (e.lmax == lmax && 16 * e.tt == hidden) k = &e;
+  if (!k) return E3_ERR_UNSUPPORTED;  // hidden in {16, 32, 64}
+  auto* P = new e3_msg_plan();
+  P->lmax = lmax; P->H = hidden; P->k = k;
+  const int H = hidden, TT = k->tt, KS = (H + 31) / 32;
+  auto ok = [&](int l1, int l2, int l3) {
+    return l1 <= lmax && l2 <= lmax && l3 <= lmax && ((l1 + l2 + l3) % 2 == 0) && l3 >= std::abs(l1 - l2) && l3 <= l1 + l2;
+  };
+  auto T = [&](int l3) { return l3 == 0 ? TT * (1 + lmax) : TT; };
+  // class-matrix row offsets: paths ordered by (l1, l2) ascending (e3_tp_plan_create), n rows each
+  const int n1[3] = {2 * H + 1, 2 * H, 2 * H}, n2[3] = {H, H, H};
+  int wrow1[3][3][3], wrow2[3][3][3];
+  for (int l3 = 0; l3 <= 2; ++l3) {
+    int r1 = 0, r2 = 0;
+    for (int l1 = 0; l1 <= 2; ++l1)
+      for (int l2 = 0; l2 <= 2; ++l2) {
+        wrow1[l1][l2][l3] = wrow2[l1][l2][l3] = -1;
+        if (l3 > lmax || !ok(l1, l2, l3)) continue;
+        wrow1[l1][l2][l3] = r1; r1 += n1[l1];
+        wrow2[l1][l2][l3] = r2; r2 += n2[l1];
+      }
+    P->K1[l3] = l3 <= lmax ? r1 : 0;
+    P->K2[l3] = l3 <= lmax ? r2 : 0;
+    P->M[l3] = l3 <= lmax ? 16 * T(l3) : 0;
+    P->rowd[l3] = (l3 <= lmax) ? wrow1[0][l3][l3] + 2 * H : 0;
+  }
+  // blocks in the kernels' order: l1 outer, then l3, then l2; (ks, t) inside a path
+  int b = 0;
+  for (int l1 = 0; l1 <= lmax; ++l1)
+    for (int l3 = 0; l3 <= lmax; ++l3)
+      for (int l2 = 0; l2 <= lmax; ++l2) {
+        if (!ok(l1, l2, l3)) continue;
+        for (int ks = 0; ks < KS; ++ks)
+          for (int t = 0; t < T(l3); ++t) {
+            const int nvalid = std::min(32, H - 32 * ks);
+            const int M = 16 * T(l3);
+            P->desc.push_back({0, l3, wrow1[l1][l2][l3] + H + 32 * ks, nvalid, M, 16 * t, b + ks * T(l3) + t});  // src rows
+            P->desc.push_back({2, l3, wrow1[l1][l2][l3] + 32 * ks, nvalid, M, 16 * t, b + ks * T(l3) + t});      // dst rows
+            P->desc.push_back({1, l3, wrow2[l1][l2][l3] + 32 * ks, nvalid, M, 16 * t, b + ks * T(l3) + t});
+          }
+        b += KS * T(l3);
+      }
+  if (b != k->nblk) { delete P; return E3_ERR_INVALID_ARG; }
+  *plan_out = P;
+  return E3_OK;
+}
+
+int e3_msg_plan_destroy(e3_msg_plan* P) {
+  if (!P) return E3_OK;
+  if (P->d_desc) (void)hipFree(P->d_desc);
+  delete P;
+  return E3_OK;
+}
+
+int64_t e3_msg_packed_bytes(const e3_msg_plan* P) { return P ? (P->k->total_floats * 4 + 255) / 256 * 256 : -1; }
+int64_t e3_msg_premix_floats_per_node(const e3_msg_plan* P) { return P ? P->k->UD : -1; }
+int e3_msg_weight_shape(const e3_msg_plan* P, int tp, int l3, int* rows, int* cols) {
+  if (!P || !rows || !cols || l3 < 0 || l3 > 2 || (tp != 1 && tp != 2)) return E3_ERR_INVALID_ARG;
+  *rows = tp == 1 ? P->K1[l3] : P->K2[l3];
+  *cols = P->M[l3];
+  return E3_OK;
+}
+
+int e3_msg_pack_weights(e3_msg_plan* P, const float* const w1[3], const float* const n1[3], const float* const w2[3],
+                        const float* const n2[3], void* packed, void* stream) {
+  if (!P || !w1 || !w2 || !packed) return E3_ERR_INVALID_ARG;
+  for (int l = 0; l <= P->lmax; ++l)
+    if (!w1[l] || !w2[l]) return E3_ERR_MISSING_WEIGHT;
+  int st = msg_ensure_device(P);
+  if (st != E3_OK) return st;
+  const MsgKernels& k = *P->k;
+  MsgPackArgs a;
+  for (int l = 0; l < 3; ++l) {
+    const bool on = l <= P->lmax;
+    a.w1[l] = on ? w1[l] : nullptr; a.w2[l] = on ? w2[l] : nullptr;
+    a.n1[l] = (on && n1) ? n1[l] : nullptr; a.n2[l] = (on && n2) ? n2[l] : nullptr;
+    a.nw1[l] = on ? (int64_t)P->K1[l] * P->M[l] : 0;
+    a.nw2[l] = on ? (int64_t)P->K2[l] * P->M[l] : 0;
+    a.rowd[l] = P->rowd[l];
+  }
+  a.M0 = P->M[0]; a.H = P->H; a.LMAX = P->lmax; a.TT = k.tt; a.NS = k.NS; a.WD = k.WD;
+  a.o_norm1 = k.o_norm1; a.o_norm2 = k.o_norm2; a.o_wd = k.o_wd; a.o_w = k.o_w; a.nblk = k.nblk;
+  hipStream_t s = (hipStream_t)stream;
+  E3_HIP_CHECK(hipMemsetAsync(packed, 0, 256, s));
+  hipLaunchKernelGGL(msg_absmax_kernel, dim3(64), dim3(256), 0, s, a, (uint32_t*)packed);
+  hipLaunchKernelGGL(msg_pack_kernel, dim3(std::min<int>((int)P->desc.size(), 512)), dim3(256), 0, s, a, P->d_desc,
+                     (int)P->desc.size(), (float*)packed);
+  E3_HIP_CHECK(hipGetLastError());
+  return E3_OK;
+}
+
+int e3_msg_forward(e3_msg_plan* P, const float* h, int64_t ld_h, int64_t N, const float* pos4, const int32_t* src,
+                   const int32_t* dst, int64_t E, const void* packed, const float* in_scale, float* premix,
+                   float* out, int64_t ld_out, int tiles_per_block, void* stream) {
+  if (!P || N < 0 || E < 0) return E3_ERR_INVALID_ARG;
+  const MsgKernels& k = *P->k;
+  if (N == 0) return E3_OK;
+  if (!h || !pos4 || !packed || !premix || !out || ld_h < k.D || ld_out < k.D || (E > 0 && (!src || !dst)))
+    return E3_ERR_INVALID_ARG;
+  if ((ld_h & 3) || ((uintptr_t)h & 15) || ((uintptr_t)premix & 15)) return E3_ERR_INVALID_ARG;  // 16-byte row gathers
+  int st = msg_ensure_device(P);
+  if (st != E3_OK) return st;
+  hipStream_t s = (hipStream_t)stream;
+  // out is an accumulation target of atomics: the rows of this launch start from zero
+  E3_HIP_CHECK(hipMemset2DAsync(out, (size_t)ld_out * 4, 0, (size_t)k.D * 4, (size_t)N, s));
+  if (E == 0) return E3_OK;
+  {
+    const int64_t ntiles = (N + 15) / 16;
+    const int grid = (int)std::min<int64_t>((ntiles + 3) / 4, 2048);
+    void* args[] = {&h, &ld_h, &N, &packed, &in_scale, &premix};
+    if (hipLaunchKernel(k.premix, dim3(grid), dim3(256), args, 0, s) != hipSuccess) return E3_ERR_HIP;
+  }
+  const int64_t ntiles = (E + 15) / 16;
+  int nwg = 256 * k.waves_per_simd;  // 4 waves per workgroup; waves_per_simd workgroups per CU
+  nwg = (int)std::min<int64_t>(nwg, (ntiles + 3) / 4);
+  nwg = std::max(8, (nwg + 7) / 8 * 8);
+  const int64_t tiles_per_wg = (ntiles + nwg - 1) / nwg;
+  int blk = tiles_per_block > 0 ? tiles_per_block : (int)std::min<int64_t>((tiles_per_wg + 3) / 4, 1 << 20);
+  if (blk < 1) blk = 1;
+  const size_t lds = (size_t)(k.lds_tab + 4 * k.lds_wave) * 4;
+  void* args[] = {&h, &ld_h, &pos4, &src, &dst, &E, &packed, &premix, &in_scale, &out, &ld_out,
+                  const_cast<int64_t*>(&tiles_per_wg), &blk};
+  if (hipLaunchKernel(k.fused, dim3(nwg), dim3(256), args, lds, s) != hipSuccess) return E3_ERR_HIP;
+  return E3_OK;
+}
+
+}  // extern "C"

@@ -30,6 +30,7 @@ struct e3_tp_plan {
   e3::TpPath* d_paths = nullptr;
   e3::TpFast fast;
   std::mutex mu;
+  int device = -1;  // the device the tables were uploaded to (the one current at first use); calls from another one fail
 };
 
 namespace e3 {
@@ -139,21 +140,34 @@ __global__ void tp_pack_kernel(const T* w0, const T* w1, const T* w2, const T* w
 static int tp_ensure_device(const e3_tp_plan* cplan) {
   auto* P = const_cast<e3_tp_plan*>(cplan);
   std::lock_guard<std::mutex> lock(P->mu);
-  if (P->d_tables) return E3_OK;
+  int cur = -1;
+  if (hipGetDevice(&cur) != hipSuccess) return E3_ERR_NO_DEVICE;
+  if (P->d_tables) return cur == P->device ? E3_OK : E3_ERR_INVALID_ARG;  // one plan = one device (create one per device)
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return E3_ERR_NO_DEVICE;
   int32_t* d = nullptr;
-  E3_HIP_CHECK(hipMalloc((void**)&d, P->h_tables.size() * sizeof(int32_t)));
-  E3_HIP_CHECK(hipMemcpy(d, P->h_tables.data(), P->h_tables.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-  size_t np = std::max<size_t>(P->h_paths.size(), 1);
-  E3_HIP_CHECK(hipMalloc((void**)&P->d_paths, np * sizeof(TpPath)));
-  if (!P->h_paths.empty())
-    E3_HIP_CHECK(hipMemcpy(P->d_paths, P->h_paths.data(), P->h_paths.size() * sizeof(TpPath), hipMemcpyHostToDevice));
+  TpPath* dpaths = nullptr;
+  auto fail = [&](int st) {
+    if (d) (void)hipFree(d);
+    if (dpaths) (void)hipFree(dpaths);
+    fast_free(&P->fast);
+    return st;
+  };
+  if (hipMalloc((void**)&d, P->h_tables.size() * sizeof(int32_t)) != hipSuccess) return fail(E3_ERR_HIP);
+  if (hipMemcpy(d, P->h_tables.data(), P->h_tables.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess)
+    return fail(E3_ERR_HIP);
+  const size_t np = std::max<size_t>(P->h_paths.size(), 1);
+  if (hipMalloc((void**)&dpaths, np * sizeof(TpPath)) != hipSuccess) return fail(E3_ERR_HIP);
+  if (!P->h_paths.empty() &&
+      hipMemcpy(dpaths, P->h_paths.data(), P->h_paths.size() * sizeof(TpPath), hipMemcpyHostToDevice) != hipSuccess)
+    return fail(E3_ERR_HIP);
+  const int st = fast_upload(&P->fast);
+  if (st != E3_OK) return fail(st);
+  P->d_paths = dpaths;
   P->dev.cpos = d;
   P->dev.ocol = d + P->dev.D1;
-  P->dev.paths = P->d_paths;
-  int st = fast_upload(&P->fast);
-  if (st != E3_OK) return st;
+  P->dev.paths = dpaths;
+  P->device = cur;
   P->d_tables = d;
   return E3_OK;
 }
@@ -602,7 +616,8 @@ int e3_tp_pack_weights(const e3_tp_plan* plan, const void* const w[6], const voi
 }
 
 int e3_tp_forward(const e3_tp_plan* plan, const void* in1, int64_t ld1, const void* in2, int64_t ld2,
-                  const void* packed, void* out, int64_t ldo, int64_t B, int dtype, void* stream) {
+                  const void* packed, void* out, int64_t ldo, int64_t B, int dtype, const float* in_scale, int exact,
+                  void* stream) {
   if (!plan || B < 0 || dtype < 0 || dtype > 2) return E3_ERR_INVALID_ARG;
   if (B == 0) return E3_OK;
   if (!in1 || !in2 || !packed || !out) return E3_ERR_INVALID_ARG;
@@ -611,18 +626,19 @@ int e3_tp_forward(const e3_tp_plan* plan, const void* in1, int64_t ld1, const vo
   int st = tp_ensure_device(plan);
   if (st != E3_OK) return st;
   hipStream_t s = (hipStream_t)stream;
-  static const bool no_fast = getenv("E3_TP_GENERIC") != nullptr;
-  if (dtype != E3_F64 && plan->fast.usable && ld2 != 0 && (!no_fast || dtype == E3_BF16)) {
+  if (dtype == E3_BF16 && exact) return E3_ERR_UNSUPPORTED;
+  if (dtype != E3_F64 && plan->fast.usable && ld2 != 0 && !exact) {
     e3_tp_segment seg = {in1, ld1, nullptr, plan->dev.D1, 0};
     return fast_forward(&plan->fast, &seg, 1, plan->dev.D1, in2, ld2, (const char*)packed + fast_section_offset(plan),
-                        out, ldo, B, 0, dtype, plan->dev.ocol, s);
+                        out, ldo, B, 0, dtype, plan->dev.ocol, in_scale, s);
   }
   return dtype == E3_F32 ? tp_launch_fwd<float>(plan, in1, ld1, in2, ld2, packed, out, ldo, B, s)
                          : tp_launch_fwd<double>(plan, in1, ld1, in2, ld2, packed, out, ldo, B, s);
 }
 
 int e3_tp_forward_fused(const e3_tp_plan* plan, const e3_tp_segment* segs, int nseg, const void* in2, int64_t ld2,
-                        const void* packed, void* out, int64_t ldo, int64_t B, int dtype, int gate, void* stream) {
+                        const void* packed, void* out, int64_t ldo, int64_t B, int dtype, int gate,
+                        const float* in_scale, void* stream) {
   if (!plan || !segs || B < 0) return E3_ERR_INVALID_ARG;
   if ((dtype != E3_F32 && dtype != E3_BF16) || !plan->fast.usable || ld2 == 0) return E3_ERR_UNSUPPORTED;
   if (B == 0) return E3_OK;
@@ -630,12 +646,12 @@ int e3_tp_forward_fused(const e3_tp_plan* plan, const e3_tp_segment* segs, int n
   int st = tp_ensure_device(plan);
   if (st != E3_OK) return st;
   return fast_forward(&plan->fast, segs, nseg, plan->dev.D1, in2, ld2, (const char*)packed + fast_section_offset(plan),
-                      out, ldo, B, gate, dtype, plan->dev.ocol, (hipStream_t)stream);
+                      out, ldo, B, gate, dtype, plan->dev.ocol, in_scale, (hipStream_t)stream);
 }
 
 int e3_tp_forward_fused_scatter(const e3_tp_plan* plan, const e3_tp_segment* segs, int nseg, const void* in2,
                                 int64_t ld2, const void* packed, const int32_t* row_node, void* out_nodes,
-                                int64_t ldo, int64_t B, int dtype, int gate, void* stream) {
+                                int64_t ldo, int64_t B, int dtype, int gate, const float* in_scale, void* stream) {
   if (!plan || !segs || !row_node || B < 0) return E3_ERR_INVALID_ARG;
   if ((dtype != E3_F32 && dtype != E3_BF16) || !gate || !plan->fast.usable || ld2 == 0) return E3_ERR_UNSUPPORTED;
   if (B == 0) return E3_OK;
@@ -643,7 +659,7 @@ int e3_tp_forward_fused_scatter(const e3_tp_plan* plan, const e3_tp_segment* seg
   int st = tp_ensure_device(plan);
   if (st != E3_OK) return st;
   return fast_forward(&plan->fast, segs, nseg, plan->dev.D1, in2, ld2, (const char*)packed + fast_section_offset(plan),
-                      out_nodes, ldo, B, gate, dtype, plan->dev.ocol, (hipStream_t)stream, row_node);
+                      out_nodes, ldo, B, gate, dtype, plan->dev.ocol, in_scale, (hipStream_t)stream, row_node);
 }
 
 int e3_tp_backward(const e3_tp_plan* plan, const void* in1, int64_t ld1, const void* in2, int64_t ld2,
@@ -667,17 +683,6 @@ int e3_tp_backward(const e3_tp_plan* plan, const void* in1, int64_t ld1, const v
 }
 
 const char* e3_tp_last_fused_kernel(void) { return fast_last_kernel(); }
-
-// diagnostic: per-phase wave-cycle sums of the MFMA kernel (E3_TP_DBG & 8); reads and clears
-int e3_tp_debug_phase_cycles(const e3_tp_plan* plan, unsigned long long out[8]) {
-  if (!plan || !out || !plan->fast.dev.prof) return E3_ERR_UNSUPPORTED;
-  E3_HIP_CHECK(hipDeviceSynchronize());
-  unsigned long long tmp[8];
-  E3_HIP_CHECK(hipMemcpy(tmp, plan->fast.dev.prof, sizeof(tmp), hipMemcpyDeviceToHost));
-  for (int i = 0; i < 8; ++i) out[i] = tmp[i];
-  E3_HIP_CHECK(hipMemset(plan->fast.dev.prof, 0, sizeof(tmp)));
-  return E3_OK;
-}
 
 int e3_tp_fused_supported(const e3_tp_plan* plan, int gate) {
   if (!plan || !plan->fast.usable) return 0;

@@ -1,89 +1,70 @@
-// fp32 MFMA kernel for the general SH tensor product (l <= 2, natural-parity classes 0e / 1o / 2e),
-// with optional fused row gather (in1 = concatenation of row-indexed segments) and fused gate.
-//
-// Structure ("K-outer, all outputs resident"): one wave owns a tile of 32 rows and keeps EVERY output
-// accumulator of those rows in registers (NT0 scalar tiles + 3*NT1 + 5*NT2 accumulators of 16 VGPRs).  It
-// then walks the input irreps blocks ("chunks" of <= 32 channels): each chunk is staged once into a small
-// LDS buffer by LDS-DMA (gathered per row when a segment carries a row index) and contracted on the
-// matrix core (v_mfma_f32_32x32x2_f32) into every output class it couples to:
-//     A operand = packed weights W'[k][32 t + (lane&31)]           (LDS when they fit, else L2)
-//     B operand = per-row feature  sum_m1 z[m1][m3] x[k][m1]        z = sum_m2 C[m1][m2][m3] Y[m2]  (per lane)
-// or, when 2 l1 + 1 < 2 l3 + 1, the raw x[k][m1] into temporaries that are folded with z afterwards.
-// So every input element is read from HBM/L2 once per tile and every output is written once; the gather,
-// the concat and the gate of the SEGNN message function never materialise in HBM.
+// Host side of the MFMA path of the general SH tensor product (l <= 2, natural-parity classes 0e / 1o / 2e): chunk plan,
+// weight packing (fp16 hi/lo split with a power-of-two scale for fp32 storage, plain bf16 for bf16 storage) and dispatch
+// to the 16-row kernel (e3_tp_mfma_r16.hip).  Shapes without an instantiation run on the generic FMA kernel (e3_tp.hip),
+// which is also the exact-fp32 / fp64 path.
 #include "e3_common.h"
-#include "cg_tables.h"
 #include "e3_tp_internal.h"
 
 #include <algorithm>
 #include <cstdlib>
-#include <type_traits>
 #include <vector>
 
 namespace e3 {
 
 #include "e3_tp_mfma_core.h"
 
-#include "e3_tp_mfma_kernel.h"
+// max |w| over the three natural-parity class matrices -> header[0] (float bits, atomicMax; zeroed by the caller)
+template <typename T>
+__global__ void fast_absmax_kernel(const T* w0, int64_t n0, const T* w1, int64_t n1, const T* w2, int64_t n2,
+                                   uint32_t* hdr) {
+  const T* w[3] = {w0, w1, w2};
+  const int64_t n[3] = {n0, n1, n2};
+  float m = 0.f;
+  for (int c = 0; c < 3; ++c)
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n[c]; i += (int64_t)gridDim.x * blockDim.x)
+      m = fmaxf(m, fabsf(to_acc(w[c][i])));
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0 && m > 0.f && m < INFINITY) atomicMax(hdr, __builtin_bit_cast(uint32_t, m));
+}
 
-// ---------------------------------------------------------------------------------------------------
-// host side
-// ---------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void fast_pack_kernel(const T* w0, const T* w1, const T* w2, const T* n0, const T* n1, const T* n2,
                                  float* packed, FDev d, const FPack* pk, int npk, const int32_t* ocol_tab) {
+  constexpr bool IO16 = std::is_same<T, bf16>::value;
   const T* w[3] = {w0, w1, w2};
   const T* nr[3] = {n0, n1, n2};
+  float* hdr = packed + ((d.Dout + 3) & ~3);
+  const float sw = IO16 ? 1.0f : pow2_scale_from_bits(reinterpret_cast<const uint32_t*>(hdr)[0], 13);
+  uint16_t* whi = reinterpret_cast<uint16_t*>(hdr + 4);
+  uint16_t* wlo = whi + d.bftotal;
   for (int r = blockIdx.x; r < npk; r += gridDim.x) {
     const FPack q = pk[r];
     const int M = d.M[q.l3], Mpad = d.Mpad[q.l3];
-    uint16_t* whi = reinterpret_cast<uint16_t*>(packed + d.wtotal + ((d.Dout + 3) & ~3));
-    uint16_t* wlo = whi + d.bftotal;
     for (int i = threadIdx.x; i < q.count * M; i += blockDim.x) {
-      int k = i / M, mm = i - k * M;
-      const float v = to_acc(w[q.l3][(int64_t)(q.orig_row + k) * M + mm]);
-      packed[d.woff[q.l3] + (size_t)(q.wrow + k) * Mpad + mm] = v;
-      // bf16 split, layout [16-row block][k half][channel][8]
-      const __bf16 h = (__bf16)v;
-      const __bf16 l = (__bf16)(v - (float)h);
+      const int k = i / M, mm = i - k * M;
+      const float v = to_acc(w[q.l3][(int64_t)(q.orig_row + k) * M + mm]) * sw;
+      // layout [16-row block][k half][channel][8]
       const size_t e = (size_t)d.bfoff[q.l3] + ((size_t)(2 * (q.wblk + (k >> 4)) + ((k >> 3) & 1)) * Mpad + mm) * 8 + (k & 7);
-      whi[e] = __builtin_bit_cast(uint16_t, h);
-      wlo[e] = __builtin_bit_cast(uint16_t, l);
+      if (IO16) {
+        whi[e] = __builtin_bit_cast(uint16_t, (__bf16)v);
+      } else {
+        const _Float16 h = (_Float16)v;
+        const _Float16 l = (_Float16)(v - (float)h);
+        whi[e] = __builtin_bit_cast(uint16_t, h);
+        wlo[e] = __builtin_bit_cast(uint16_t, l);
+      }
     }
   }
-  if (blockIdx.x == 0)
+  if (blockIdx.x == 0) {
     for (int l3 = 0; l3 < 3; ++l3) {
       const int width = 2 * l3 + 1;
       for (int i = threadIdx.x; i < d.M[l3] * width; i += blockDim.x) {
-        int mm = i / width, comp = i - mm * width;
-        packed[d.wtotal + ocol_tab[d.ooff[l3] + mm] + comp] = nr[l3] ? to_acc(nr[l3][i]) : 1.0f;
+        const int mm = i / width, comp = i - mm * width;
+        packed[ocol_tab[d.ooff[l3] + mm] + comp] = nr[l3] ? to_acc(nr[l3][i]) : 1.0f;
       }
     }
-}
-
-// Instantiated signatures = the tensor products of the SEGNN forward (H <= 32 per block):
-//   l_max 1: embed (0,1 -> hid), msg1 (0,1,0,1,0 -> gated), msg2 (0,1 -> gated), upd1 (0,1,0,1 -> gated),
-//            upd2 (0,1 -> hid), readout (0,1 -> 1o);   l_max 2: the same with (0,1,2) blocks.
-std::vector<FastKernelEntry> fast_kernels_part1();  // e3_tp_mfma_p1.hip: l_max 2 message TP #1
-std::vector<FastKernelEntry> fast_kernels_part2();  // e3_tp_mfma_p2.hip: l_max 2 message TP #2, update TP #1
-static const std::vector<FastKernelEntry>& fast_kernels() {
-  static const std::vector<FastKernelEntry> k = [] {
-    std::vector<FastKernelEntry> v = {
-        E3_FAST(1, 1, 1, 0, 0, 1),       E3_FAST(1, 2, 1, 0, 0, 1, 0, 1, 0), E3_FAST(1, 2, 1, 0, 0, 1),
-        E3_FAST(1, 2, 1, 0, 0, 1, 0, 1), E3_FAST(1, 0, 1, 0, 0, 1),
-        E3_FAST(2, 1, 1, 1, 0, 1),       E3_FAST(2, 1, 1, 1, 0, 1, 2),       E3_FAST(2, 0, 1, 0, 0, 1, 2),
-    };
-    for (auto& e : fast_kernels_part1()) v.push_back(e);
-    for (auto& e : fast_kernels_part2()) v.push_back(e);
-    return v;
-  }();
-  return k;
-}
-
-static const FastKernelEntry* find_fast(int lsh, int a, int b, int c, const std::vector<int>& l1s) {
-  for (auto& e : fast_kernels())
-    if (e.lsh == lsh && e.nt0 == a && e.nt1 == b && e.nt2 == c && e.l1s == l1s) return &e;
-  return nullptr;
+    if (threadIdx.x == 0) { hdr[1] = sw; hdr[2] = 1.0f / sw; }
+  }
 }
 
 int fast_plan_init(TpFast* F, const int n[6], const int M[6], int lmax_sh, int Dout, int Dy,
@@ -104,10 +85,6 @@ int fast_plan_init(TpFast* F, const int n[6], const int M[6], int lmax_sh, int D
     d.ooff[l3] = ocol_off[cls3[l3]];
   }
   d.lsh = lmax_sh;
-  d.bf = getenv("E3_TP_EXACT") ? 0 : 1;
-  d.dbg = getenv("E3_TP_DBG") ? atoi(getenv("E3_TP_DBG")) : 0;
-  d.prof = nullptr;  // timing-only diagnostics, results are wrong when set  // default: bf16-split operands (fp32-grade accuracy)
-  int next_row[3] = {0, 0, 0};
   int next_blk[3] = {0, 0, 0};
   int chan_seen[3] = {0, 0, 0};  // channels of in class l1 seen so far
   for (auto& b : in_blocks) {
@@ -119,18 +96,14 @@ int fast_plan_init(TpFast* F, const int n[6], const int M[6], int lmax_sh, int D
       ch.l1 = l1;
       for (int l2 = 0; l2 < 3; ++l2)
         for (int l3 = 0; l3 < 3; ++l3) {
-          ch.wrow[l2][l3] = -1;
           ch.wblk[l2][l3] = -1;
           if (l2 > lmax_sh || d.M[l3] == 0 || ((l1 + l2 + l3) & 1) || l3 < std::abs(l1 - l2) || l3 > l1 + l2) continue;
-          // original row offset of path (l1,l2) in class cls3[l3]
-          int orig = -1;
+          int orig = -1;  // original row offset of path (l1, l2) in class cls3[l3]
           for (auto& p : paths_by_class[cls3[l3]])
             if (p.l1 == l1 && p.l2 == l2) orig = p.wrow;
           if (orig < 0) continue;
-          ch.wrow[l2][l3] = next_row[l3];
           ch.wblk[l2][l3] = next_blk[l3];
-          F->h_pack.push_back({l3, orig + chan_seen[l1] + 0, ch.count, next_row[l3], next_blk[l3]});
-          next_row[l3] += (ch.count + 1) & ~1;
+          F->h_pack.push_back({l3, orig + chan_seen[l1], ch.count, next_blk[l3]});
           next_blk[l3] += (ch.count + 15) >> 4;
         }
       chan_seen[l1] += ch.count;
@@ -140,17 +113,11 @@ int fast_plan_init(TpFast* F, const int n[6], const int M[6], int lmax_sh, int D
         ch.rows_per[m] = 64 / ch.S[m];
         ch.inv[m] = (65536 + ch.S[m] - 1) / ch.S[m];
         for (int ln = 0; ln < 64; ++ln)
-          if (((ln * ch.inv[m]) >> 16) != ln / ch.S[m]) return E3_ERR_UNSUPPORTED;
+          if (((ln * ch.inv[m]) >> 16) != ln / ch.S[m]) return E3_OK;
       }
       F->h_chunks.push_back(ch);
     }
   }
-  int woff = 0;
-  for (int l3 = 0; l3 < 3; ++l3) {
-    d.woff[l3] = woff;
-    woff += next_row[l3] * d.Mpad[l3];
-  }
-  d.wtotal = woff;
   int bfo = 0;
   for (int l3 = 0; l3 < 3; ++l3) {
     d.bfoff[l3] = bfo;
@@ -158,32 +125,8 @@ int fast_plan_init(TpFast* F, const int n[6], const int M[6], int lmax_sh, int D
   }
   d.bftotal = bfo;
   d.nchunks = (int)F->h_chunks.size();
-  if (d.nchunks == 0 || d.wtotal == 0) return E3_OK;
-  std::vector<int> l1s;
-  for (auto& c : F->h_chunks) l1s.push_back(c.l1);
-  if (!find_fast(lmax_sh, d.NT[0], d.NT[1], d.NT[2], l1s)) return E3_OK;
-  // LDS plan: [weights?][normcol][ocol][nwaves x (nbuf chunk buffers + Y tile)], once per storage class
-  size_t tables = (size_t)((Dout + 4 + 15) & ~15) * 4 + (size_t)((ntab + 15) & ~15) * 4;
-  auto lds_plan = [&](FDev& dd, size_t wbytes, int chunk_dwords, size_t* lds_bytes) -> bool {
-    auto per_wave = [&](int nbuf) { return (size_t)(nbuf * chunk_dwords + 320) * 4; };
-    auto fit = [&](size_t fixed, int nbuf) -> int {
-      return fixed + per_wave(nbuf) <= (size_t)kFastLds ? (int)std::min<size_t>(((size_t)kFastLds - fixed) / per_wave(nbuf), 4) : 0;
-    };
-    // One chunk buffer per wave and as many waves as fit: measured, a second buffer never paid (the wave that
-    // issues the copies is the one that consumes them; 3 double-buffered waves lost to 4 single-buffered ones on
-    // every kernel of the SEGNN forward).  E3_TP_NBUF=2 keeps the double-buffered variant reachable.
-    const int w1 = fit(tables + wbytes, 1);
-    if (w1 >= 3) { dd.w_in_lds = 1; dd.nbuf = 1; dd.nwaves = w1; }
-    else { dd.w_in_lds = 0; dd.nbuf = 1; dd.nwaves = fit(tables, 1); }
-    if (const char* e = getenv("E3_TP_NBUF")) { int v = atoi(e); if (v == 1 || (v == 2 && dd.w_in_lds && fit(tables + wbytes, 2) >= 1)) { dd.nbuf = v; dd.nwaves = fit(tables + (dd.w_in_lds ? wbytes : 0), v); } }
-    *lds_bytes = tables + (dd.w_in_lds ? wbytes : 0) + (size_t)dd.nwaves * per_wave(dd.nbuf);
-    return dd.nwaves >= 1 && *lds_bytes <= (size_t)kFastLds;
-  };
-  F->dev16 = d;
-  const bool ok32 = lds_plan(d, d.bf ? (size_t)d.bftotal * 4 : (size_t)d.wtotal * 4, kChunkFloats, &F->lds_bytes);
-  const bool ok16 = lds_plan(F->dev16, (size_t)d.bftotal * 2, kChunk16, &F->lds_bytes16);
-  if (!ok32 || !ok16) return E3_OK;
-  F->usable = true;
+  if (d.nchunks == 0 || d.bftotal == 0) return E3_OK;
+  F->usable = r16_supported(F);
   return E3_OK;
 }
 
@@ -194,22 +137,8 @@ int fast_upload(TpFast* F) {
   E3_HIP_CHECK(hipMalloc((void**)&F->d_pack, std::max<size_t>(F->h_pack.size(), 1) * sizeof(FPack)));
   if (!F->h_pack.empty())
     E3_HIP_CHECK(hipMemcpy(F->d_pack, F->h_pack.data(), F->h_pack.size() * sizeof(FPack), hipMemcpyHostToDevice));
-  if (F->dev.dbg & 8) {
-    unsigned long long* pr = nullptr;
-    E3_HIP_CHECK(hipMalloc((void**)&pr, 8 * sizeof(unsigned long long)));
-    E3_HIP_CHECK(hipMemset(pr, 0, 8 * sizeof(unsigned long long)));
-    F->dev.prof = pr;
-    F->dev16.prof = pr;
-  }
   E3_HIP_CHECK(hipMalloc((void**)&F->d_dev, sizeof(FDev)));
   E3_HIP_CHECK(hipMemcpy(F->d_dev, &F->dev, sizeof(FDev), hipMemcpyHostToDevice));
-  E3_HIP_CHECK(hipMalloc((void**)&F->d_dev16, sizeof(FDev)));
-  E3_HIP_CHECK(hipMemcpy(F->d_dev16, &F->dev16, sizeof(FDev), hipMemcpyHostToDevice));
-  for (auto& e : fast_kernels())
-    for (int f = 0; f < 3; ++f)
-      for (int a = 0; a < 2; ++a)
-        for (int b = 0; b < 2; ++b)
-          E3_HIP_CHECK(hipFuncSetAttribute(e.fn[f][a][b], hipFuncAttributeMaxDynamicSharedMemorySize, kFastLds));
   return E3_OK;
 }
 
@@ -217,12 +146,12 @@ void fast_free(TpFast* F) {
   if (F->d_chunks) (void)hipFree(F->d_chunks);
   if (F->d_pack) (void)hipFree(F->d_pack);
   if (F->d_dev) (void)hipFree(F->d_dev);
-  if (F->d_dev16) (void)hipFree(F->d_dev16);
+  F->d_chunks = nullptr; F->d_pack = nullptr; F->d_dev = nullptr;
 }
 
 int64_t fast_packed_bytes(const TpFast* F) {
   if (!F->usable) return 0;
-  int64_t words = (int64_t)F->dev.wtotal + ((F->dev.Dout + 3) & ~3) + F->dev.bftotal;  // fp32 W' | normcol | Whi+Wlo
+  const int64_t words = ((F->dev.Dout + 3) & ~3) + 4 + F->dev.bftotal;  // normcol | header | Whi + Wlo (2 x 2 bytes each)
   return (words * 4 + 255) / 256 * 256;
 }
 
@@ -230,16 +159,25 @@ int fast_pack(const TpFast* F, const void* const w[6], const void* const n[6], i
               const int32_t* ocol_tab, hipStream_t s) {
   if (!F->usable) return E3_OK;
   E3_HIP_CHECK(hipMemsetAsync(packed, 0, (size_t)fast_packed_bytes(F), s));
-  int npk = (int)F->h_pack.size();
-  dim3 grid(std::max(1, std::min(npk, 256)));
-  if (dtype == E3_BF16)
+  const int npk = (int)F->h_pack.size();
+  const dim3 grid(std::max(1, std::min(npk, 256)));
+  const FDev& d = F->dev;
+  uint32_t* hdr = reinterpret_cast<uint32_t*>((float*)packed + ((d.Dout + 3) & ~3));
+  // element counts of the class matrices: rows = sum over the packed pieces is not the full matrix when a class has
+  // unreachable rows, so take them from the pack list's extent
+  int64_t rows[3] = {0, 0, 0};
+  for (auto& q : F->h_pack) rows[q.l3] = std::max<int64_t>(rows[q.l3], q.orig_row + q.count);
+  if (dtype == E3_BF16) {
     hipLaunchKernelGGL(fast_pack_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)w[0], (const bf16*)w[3],
                        (const bf16*)w[4], (const bf16*)(n ? n[0] : nullptr), (const bf16*)(n ? n[3] : nullptr),
-                       (const bf16*)(n ? n[4] : nullptr), (float*)packed, F->dev, F->d_pack, npk, ocol_tab);
-  else
+                       (const bf16*)(n ? n[4] : nullptr), (float*)packed, d, F->d_pack, npk, ocol_tab);
+  } else {
+    hipLaunchKernelGGL(fast_absmax_kernel<float>, dim3(64), dim3(256), 0, s, (const float*)w[0], rows[0] * d.M[0],
+                       (const float*)w[3], rows[1] * d.M[1], (const float*)w[4], rows[2] * d.M[2], hdr);
     hipLaunchKernelGGL(fast_pack_kernel<float>, grid, dim3(256), 0, s, (const float*)w[0], (const float*)w[3],
                        (const float*)w[4], (const float*)(n ? n[0] : nullptr), (const float*)(n ? n[3] : nullptr),
-                       (const float*)(n ? n[4] : nullptr), (float*)packed, F->dev, F->d_pack, npk, ocol_tab);
+                       (const float*)(n ? n[4] : nullptr), (float*)packed, d, F->d_pack, npk, ocol_tab);
+  }
   E3_HIP_CHECK(hipGetLastError());
   return E3_OK;
 }
@@ -250,11 +188,10 @@ const char* fast_last_kernel() { return g_last_kernel; }
 
 int fast_forward(const TpFast* F, const e3_tp_segment* segs, int nseg, int D1, const void* in2, int64_t ld2,
                  const void* packed, void* out, int64_t ldo, int64_t B, int gate, int dtype, const int32_t* ocol_tab,
-                 hipStream_t s, const int32_t* scatter) {
+                 const float* in_scale, hipStream_t s, const int32_t* scatter) {
   if (!F->usable) return E3_ERR_UNSUPPORTED;
   const bool io16 = dtype == E3_BF16;
-  const FDev& d = io16 ? F->dev16 : F->dev;
-  const int mode = io16 ? 2 : (d.bf ? 1 : 0);
+  const FDev& d = F->dev;
   if (nseg < 1 || nseg > 4) return E3_ERR_INVALID_ARG;
   SegArgs sa;
   int col = 0;
@@ -284,30 +221,9 @@ int fast_forward(const TpFast* F, const e3_tp_segment* segs, int nseg, int D1, c
         d.NT[1] > 1 || d.NT[2] > 1)
       return E3_ERR_UNSUPPORTED;
   }
-  {
-    int r = fast_forward_r16(F, &sa, in2, ld2, packed, out, ldo, B, gate, mode, ocol_tab, s);
-    if (r == 0) r = fast_forward_ab(F, &sa, in2, ld2, packed, out, ldo, B, gate, mode, ocol_tab, s);
-    if (r == 1) return E3_OK;
-    if (r < 0) return -r;
-    if (scatter) return E3_ERR_UNSUPPORTED;  // only the two-wave kernel has the fused segment-sum
-  }
-  std::vector<int> l1s;
-  for (auto& c : F->h_chunks) l1s.push_back(c.l1);
-  const FastKernelEntry* e = find_fast(d.lsh, d.NT[0], d.NT[1], d.NT[2], l1s);
-  if (!e) return E3_ERR_UNSUPPORTED;
-  int64_t ntiles = (B + 31) / 32;
-  int grid = (int)std::min<int64_t>((ntiles + d.nwaves - 1) / d.nwaves, 256);
-  const float* in2f = (const float*)in2;
-  const float* pk = (const float*)packed;
-  void* outf = out;
-  const FDev* dd = io16 ? F->d_dev16 : F->d_dev;
-  const size_t lds_bytes = io16 ? F->lds_bytes16 : F->lds_bytes;
-  const FChunk* dc = F->d_chunks;
-  void* args[] = {&sa, &in2f, &ld2, &pk, &outf, &ldo, &B, &dd, &dc, &ocol_tab};
-  E3_HIP_CHECK(hipLaunchKernel(e->fn[mode][d.w_in_lds ? 1 : 0][gate ? 1 : 0], dim3(grid), dim3(64 * d.nwaves), args,
-                               lds_bytes, s));
-  fast_note_kernel("e3::tp_fwd_mfma_kernel");
-  return E3_OK;
+  const int r = fast_forward_r16(F, &sa, in2, ld2, packed, out, ldo, B, gate, io16 ? 1 : 0, ocol_tab, in_scale, s);
+  if (r == 1) return E3_OK;
+  return r < 0 ? -r : E3_ERR_UNSUPPORTED;
 }
 
 }  // namespace e3

@@ -10,31 +10,67 @@
 // Lane = (row = lane & 15, k group g = lane >> 4).  B operand: features of the lane's own row for the 8 channels of its
 // k group (the same 2*D1 ds_read_b128 as the 32-row kernel's half).  A operand: W[k = 8g + i][channel = lane & 15] -- the
 // packed [16-row block][k half][channel][8] layout already serves it: uint4 index (2 * wblk + g) * Mpad + channel.
-// Accumulator: channels 4g + r (r < 4) of the lane's row.  Operand mode: fp32 storage with bf16x3-split operands (MODE 1)
-// or bf16 storage (MODE 2), as in the other kernels.  Default for fp32 storage (see r16_level).
+// Accumulator: channels 4g + r (r < 4) of the lane's row.  Operand mode: fp32 storage with fp16 (hi, lo)-split operands on
+// v_mfma_f32_16x16x32_f16 (MODE 1: three products per fp32 product, operands scaled by powers of two -- split2_f16 in
+// e3_tp_mfma_core.h) or bf16 storage on v_mfma_f32_16x16x32_bf16 (MODE 2).
 #include "e3_common.h"
 #include "cg_tables.h"
 #include "e3_tp_internal.h"
 
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
+#include <utility>
 #include <vector>
 
 namespace e3 {
 
 #include "e3_tp_mfma_core.h"
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+// one product group: acc[t] += A[t] * B for NT tiles, bf16 storage (one MFMA) or fp16-split fp32 (three)
+template <int NT16, bool IO16, int STRIDE>
+__device__ __forceinline__ void mma_group(const uint4 (&ah)[NT16], const uint4 (&al)[IO16 ? 1 : NT16], const uint4 bh,
+                                          const uint4 bl, f32x4* acc) {
+  if constexpr (IO16) {
+#pragma unroll
+    for (int t = 0; t < NT16; ++t)
+      acc[t * STRIDE] = mfma16(__builtin_bit_cast(bf16x8, ah[t]), __builtin_bit_cast(bf16x8, bh), acc[t * STRIDE]);
+  } else {
+    // product-major order: consecutive MFMAs write different accumulators
+#pragma unroll
+    for (int t = 0; t < NT16; ++t)
+      acc[t * STRIDE] = mfma16h(__builtin_bit_cast(f16x8, ah[t]), __builtin_bit_cast(f16x8, bh), acc[t * STRIDE]);
+#pragma unroll
+    for (int t = 0; t < NT16; ++t)
+      acc[t * STRIDE] = mfma16h(__builtin_bit_cast(f16x8, ah[t]), __builtin_bit_cast(f16x8, bl), acc[t * STRIDE]);
+#pragma unroll
+    for (int t = 0; t < NT16; ++t)
+      acc[t * STRIDE] = mfma16h(__builtin_bit_cast(f16x8, al[t]), __builtin_bit_cast(f16x8, bh), acc[t * STRIDE]);
+  }
+}
+
+// 8 fp32 features -> B operand(s): bf16 (rounded once) or fp16 (hi, lo)
+template <bool IO16>
+__device__ __forceinline__ void pack_b(const float (&f)[8], uint4& bh, uint4& bl) {
+  uint32_t ph[4], pl[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if constexpr (IO16)
+      ph[q] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{f[2 * q], f[2 * q + 1]}, bf16x2_t));
+    else
+      split2_f16(f[2 * q], f[2 * q + 1], ph[q], pl[q]);
+  }
+  bh = uint4{ph[0], ph[1], ph[2], ph[3]};
+  bl = uint4{pl[0], pl[1], pl[2], pl[3]};
 }
 
 
 // this lane's operand slice of a staged chunk: 8 channels (k group g) x D1 components, read ONCE per chunk and shared
 // by every path of the chunk
 template <int L1, bool IO16>
-__device__ __forceinline__ void load_x16(const float* __restrict__ xr, const int g, float (&x)[8][2 * L1 + 1]) {
+__device__ __forceinline__ void load_x16(const float* __restrict__ xr, const int g, const float xs,
+                                         float (&x)[8][2 * L1 + 1]) {
   constexpr int D1 = 2 * L1 + 1;
   if constexpr (IO16) {
     const uint4* xv = reinterpret_cast<const uint4*>(reinterpret_cast<const uint32_t*>(xr) + 4 * g * D1);
@@ -53,7 +89,8 @@ __device__ __forceinline__ void load_x16(const float* __restrict__ xr, const int
 #pragma unroll
     for (int u = 0; u < 2 * D1; ++u) {
       const float4 v = xv[u];
-      (&x[0][0])[4 * u + 0] = v.x; (&x[0][0])[4 * u + 1] = v.y; (&x[0][0])[4 * u + 2] = v.z; (&x[0][0])[4 * u + 3] = v.w;
+      (&x[0][0])[4 * u + 0] = v.x * xs; (&x[0][0])[4 * u + 1] = v.y * xs;
+      (&x[0][0])[4 * u + 2] = v.z * xs; (&x[0][0])[4 * u + 3] = v.w * xs;
     }
   }
 }
@@ -74,6 +111,7 @@ __device__ __forceinline__ void run16(const float (&x)[8][2 * L1 + 1], const boo
     ah[t] = whi[16 * t];
     if constexpr (!IO16) al[t] = wlo[16 * t];
   }
+  // z[a][c] = sum_b C[a][b][c] Y_l2[b] of THIS lane's row (features and accumulator columns both belong to row lane & 15)
   float z[D1][D3];
 #pragma unroll
   for (int a = 0; a < D1; ++a)
@@ -87,50 +125,24 @@ __device__ __forceinline__ void run16(const float (&x)[8][2 * L1 + 1], const boo
           s = have ? __builtin_fmaf((float)C::v[a][b][c], y[L2 * L2 + b], s) : (float)C::v[a][b][c] * y[L2 * L2 + b];
           have = true;
         }
-      z[a][c] = live ? s : 0.f;  // a dead k group contributes nothing (its x reads are clamped, not meaningful)
+      z[a][c] = s;
     }
   if constexpr (L1 == 0 && D3 > 1) {
     // scalar input channels into a vector output: out[c] = z[0][c] * (W . x) -- contract the raw channels ONCE into a
     // temporary tile and fold with z afterwards (one feature build and one MFMA group instead of D3 of each)
-    uint32_t ph[4], pl[4];
+    float f[8];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float f0 = live ? x[2 * q][0] : 0.f, f1 = live ? x[2 * q + 1][0] : 0.f;
-      ph[q] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{f0, f1}, bf16x2_t));
-      if constexpr (!IO16) {
-        const float h0 = __builtin_bit_cast(float, ph[q] << 16), h1 = __builtin_bit_cast(float, ph[q] & 0xffff0000u);
-        pl[q] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{f0 - h0, f1 - h1}, bf16x2_t));
-      }
-    }
-    const bf16x8 bh = __builtin_bit_cast(bf16x8, uint4{ph[0], ph[1], ph[2], ph[3]});
+    for (int i = 0; i < 8; ++i) f[i] = live ? x[i][0] : 0.f;  // a dead k group contributes nothing (its x reads are clamped)
+    uint4 bh, bl;
+    pack_b<IO16>(f, bh, bl);
     f32x4 T[NT16];
 #pragma unroll
-    for (int t = 0; t < NT16; ++t) T[t] = mfma16(__builtin_bit_cast(bf16x8, ah[t]), bh, f32x4{0.f, 0.f, 0.f, 0.f});
-    if constexpr (!IO16) {
-      const bf16x8 bl = __builtin_bit_cast(bf16x8, uint4{pl[0], pl[1], pl[2], pl[3]});
-#pragma unroll
-      for (int t = 0; t < NT16; ++t) T[t] = mfma16(__builtin_bit_cast(bf16x8, ah[t]), bl, T[t]);
-#pragma unroll
-      for (int t = 0; t < NT16; ++t) T[t] = mfma16(__builtin_bit_cast(bf16x8, al[t]), bh, T[t]);
-    }
-    // z of THIS lane's row scales its own accumulator column: the output tile holds channels x (this lane's row)
-    float zr[D3];
-#pragma unroll
-    for (int c = 0; c < D3; ++c) {
-      float sz = 0.f;
-      bool have = false;
-#pragma unroll
-      for (int b = 0; b < D2; ++b)
-        if (C::v[0][b][c] != 0.0) {
-          sz = have ? __builtin_fmaf((float)C::v[0][b][c], y[L2 * L2 + b], sz) : (float)C::v[0][b][c] * y[L2 * L2 + b];
-          have = true;
-        }
-      zr[c] = sz;
-    }
+    for (int t = 0; t < NT16; ++t) T[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    mma_group<NT16, IO16, 1>(ah, al, bh, bl, &T[0]);
 #pragma unroll
     for (int t = 0; t < NT16; ++t)
 #pragma unroll
-      for (int c = 0; c < D3; ++c) acc[t][c] += T[t] * zr[c];
+      for (int c = 0; c < D3; ++c) acc[t][c] += T[t] * z[0][c];
     __builtin_amdgcn_sched_barrier(0);
     return;
   }
@@ -151,30 +163,11 @@ __device__ __forceinline__ void run16(const float (&x)[8][2 * L1 + 1], const boo
           have = true;
         }
       }
-      f[i] = b;
+      f[i] = live ? b : 0.f;
     }
-    uint32_t ph[4], pl[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      ph[q] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{f[2 * q], f[2 * q + 1]}, bf16x2_t));
-      if constexpr (!IO16) {
-        const float h0 = __builtin_bit_cast(float, ph[q] << 16), h1 = __builtin_bit_cast(float, ph[q] & 0xffff0000u);
-        pl[q] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{f[2 * q] - h0, f[2 * q + 1] - h1}, bf16x2_t));
-      }
-    }
-    const bf16x8 bh = __builtin_bit_cast(bf16x8, uint4{ph[0], ph[1], ph[2], ph[3]});
-    if constexpr (IO16) {
-#pragma unroll
-      for (int t = 0; t < NT16; ++t) acc[t][c] = mfma16(__builtin_bit_cast(bf16x8, ah[t]), bh, acc[t][c]);
-    } else {
-      const bf16x8 bl = __builtin_bit_cast(bf16x8, uint4{pl[0], pl[1], pl[2], pl[3]});
-#pragma unroll
-      for (int t = 0; t < NT16; ++t) acc[t][c] = mfma16(__builtin_bit_cast(bf16x8, ah[t]), bh, acc[t][c]);
-#pragma unroll
-      for (int t = 0; t < NT16; ++t) acc[t][c] = mfma16(__builtin_bit_cast(bf16x8, ah[t]), bl, acc[t][c]);
-#pragma unroll
-      for (int t = 0; t < NT16; ++t) acc[t][c] = mfma16(__builtin_bit_cast(bf16x8, al[t]), bh, acc[t][c]);
-    }
+    uint4 bh, bl;
+    pack_b<IO16>(f, bh, bl);
+    mma_group<NT16, IO16, D3>(ah, al, bh, bl, &acc[0][c]);
   }
   __builtin_amdgcn_sched_barrier(0);
 }
@@ -197,7 +190,8 @@ __global__ __launch_bounds__(256, r16_waves_per_simd(NT2)) void tp_fwd_mfma_r16_
                                                                   const float* __restrict__ packed, void* __restrict__ outv,
                                                                   int64_t ldo, int64_t B, const FDev* __restrict__ dp,
                                                                   const FChunk* __restrict__ chunks,
-                                                                  const int32_t* __restrict__ ocol_tab) {
+                                                                  const int32_t* __restrict__ ocol_tab,
+                                                                  const float* __restrict__ in_scale) {
   static_assert(MODE == 1 || MODE == 2, "bf16-pipe modes only");
   constexpr bool IO16 = MODE == 2;
   constexpr int CHUNK = r16_chunk(r16_max({L1S...}), NT2 > 0 ? 2 : (NT1 > 0 ? 1 : 0));
@@ -207,13 +201,12 @@ __global__ __launch_bounds__(256, r16_waves_per_simd(NT2)) void tp_fwd_mfma_r16_
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nwaves = blockDim.x >> 6;
   const int j = lane & 15, g = lane >> 4;
-  const int Dout = dp->Dout, Dy = dp->Dy, wtotal = dp->wtotal, nchunks = dp->nchunks;
+  const int Dout = dp->Dout, Dy = dp->Dy, nchunks = dp->nchunks;
   int cM[3], cMpad[3], cOoff[3], cBfoff[3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) { cM[c] = dp->M[c]; cMpad[c] = dp->Mpad[c]; cOoff[c] = dp->ooff[c]; cBfoff[c] = dp->bfoff[c]; }
   const int ntab = dp->ntab;
   const int bftotal = dp->bftotal;
-  const int dbg = dp->dbg;
 
   // LDS: [normcol (+4 ones) | ocol | per wave: chunk buffer | Y tile (16 x 9, padded to 160)]
   float* nrm = lds;
@@ -221,27 +214,21 @@ __global__ __launch_bounds__(256, r16_waves_per_simd(NT2)) void tp_fwd_mfma_r16_
   float* wbase = reinterpret_cast<float*>(ocl + ((ntab + 15) & ~15));
   float* cbuf = wbase + (size_t)wave * (CHUNK + 160);
   float* ybuf = cbuf + CHUNK;
-  for (int i = tid; i < Dout; i += blockDim.x) nrm[i] = packed[wtotal + i];
+  // operand scales (powers of two): the weights were packed as w * sw, the input features are multiplied by xs on the way
+  // into the B operands; both leave through the per-column norm table
+  const float* hdr = packed + ((Dout + 3) & ~3);
+  const float xs = (!IO16 && in_scale) ? in_scale[0] : 1.0f;
+  const float unscale = IO16 ? 1.0f : hdr[2] * (in_scale ? in_scale[1] : 1.0f);
+  for (int i = tid; i < Dout; i += blockDim.x) nrm[i] = packed[i] * unscale;
   if (tid < 4) nrm[Dout + tid] = 1.f;
   for (int i = tid; i < ntab; i += blockDim.x) ocl[i] = ocol_tab[i];
   __syncthreads();
-  const float* wglob = packed + wtotal + ((Dout + 3) & ~3);
+  const float* wglob = hdr + 4;
   const uint4* whi_base = reinterpret_cast<const uint4*>(wglob);
   const uint4* wlo_base = reinterpret_cast<const uint4*>(wglob + (bftotal >> 1));
 
   const int64_t ntiles = (B + 15) / 16;
   const int64_t tstride = (int64_t)gridDim.x * nwaves;
-  unsigned long long* const prof = dp->prof;
-  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
-  auto tick = [&](int phase) {
-    if (prof) {
-      const unsigned long long now = __builtin_amdgcn_s_memtime();
-      tacc[phase] += now - tlast;
-      tlast = now;
-    }
-  };
-  if (prof) tlast = __builtin_amdgcn_s_memtime();
-
   int mc0 = 0, mc1 = 0, mc2 = 0, mc3 = 0, mn0 = 0, mn1 = 0, mn2 = 0, mn3 = 0;
   auto fetch_ids = [&](int64_t t) {
     const int64_t r = t * 16 + j;
@@ -348,7 +335,6 @@ __global__ __launch_bounds__(256, r16_waves_per_simd(NT2)) void tp_fwd_mfma_r16_
       }
     }
     stage(0, cbuf);
-    tick(0);
 
     constexpr int T0 = 2 * NT0, T1 = 2 * NT1, T2 = 2 * NT2;  // 16-channel tiles
     f32x4 a0[T0 > 0 ? T0 : 1][1], a1[T1 > 0 ? T1 : 1][3], a2[T2 > 0 ? T2 : 1][5];
@@ -369,7 +355,6 @@ __global__ __launch_bounds__(256, r16_waves_per_simd(NT2)) void tp_fwd_mfma_r16_
       constexpr int L1 = Seq::at(decltype(itag)::value);
       wait_vm0();
       wave_sync_lds();
-      tick(1);
       if (ci == 0) {
 #pragma unroll
         for (int q = 0; q < 9; ++q) y[q] = (q < Dy) ? ybuf[j * Dy + q] : 0.f;
@@ -382,22 +367,19 @@ __global__ __launch_bounds__(256, r16_waves_per_simd(NT2)) void tp_fwd_mfma_r16_
       const int gw = live ? g : (g & 1);       // keep the (unused) weight reads of a dead group inside the matrix
       const float* xrl = live ? xr : cbuf;     // and its x reads inside the buffer
       float x[8][2 * L1 + 1];
-      load_x16<L1, IO16>(xrl, live ? g : 0, x);
+      load_x16<L1, IO16>(xrl, live ? g : 0, xs, x);
 #define E3_RUN(L2v, L3v, ACC, NTv)                                                                             \
   if constexpr (Slots::valid(L1, L2v, L3v)) {                                                                  \
     static_assert(CG<L1, L2v, L3v>::valid, "path bookkeeping");                                                \
     const size_t o = (size_t)(cBfoff[L3v] >> 3) + (size_t)(2 * ch.wblk[L2v][L3v] + gw) * cMpad[L3v] + j;       \
-    if (!(dbg & 4))                                                                                            \
-      run16<L1, L2v, L3v, 2 * NTv, IO16>(x, live, whi_base + o, wlo_base + o, y, ACC);                          \
+    run16<L1, L2v, L3v, 2 * NTv, IO16>(x, live, whi_base + o, wlo_base + o, y, ACC);                            \
   }
       E3_RUN(0, 0, a0, NT0) E3_RUN(1, 0, a0, NT0) E3_RUN(2, 0, a0, NT0)
       E3_RUN(0, 1, a1, NT1) E3_RUN(1, 1, a1, NT1) E3_RUN(2, 1, a1, NT1)
       E3_RUN(0, 2, a2, NT2) E3_RUN(1, 2, a2, NT2) E3_RUN(2, 2, a2, NT2)
 #undef E3_RUN
-      tick(3);
       wave_sync_lds();
       if (ci + 1 < nchunks) stage(ci + 1, cbuf);
-      tick(2);
       ++ci;
     };
     for_each_index(process, std::make_index_sequence<sizeof...(L1S)>{});
@@ -420,7 +402,6 @@ __global__ __launch_bounds__(256, r16_waves_per_simd(NT2)) void tp_fwd_mfma_r16_
 #pragma unroll
         for (int c = 0; c < D; ++c) ot[j * TS + D * chan_of(q) + c] = val(q, c);
       wave_sync_lds();
-      tick(4);
       if constexpr (SCAT) {
         for (int cb = 0; cb < 32 * D; cb += 64) {
           const int lc = cb + lane;
@@ -434,13 +415,13 @@ __global__ __launch_bounds__(256, r16_waves_per_simd(NT2)) void tp_fwd_mfma_r16_
           for (int r = 0; r < 16; ++r) {
             const int dn = __builtin_amdgcn_readlane(sd, r);
             if (dn != cur) {
-              if (cur >= 0 && cok && !(dbg & 1)) __builtin_amdgcn_global_atomic_fadd_f32(obase + (int64_t)cur * ldo, acc);
+              if (cur >= 0 && cok) __builtin_amdgcn_global_atomic_fadd_f32(obase + (int64_t)cur * ldo, acc);
               acc = 0.f;
               cur = dn;
             }
             if (dn >= 0) acc = __builtin_fmaf(src[r * TS], nv, acc);
           }
-          if (cur >= 0 && cok && !(dbg & 1)) __builtin_amdgcn_global_atomic_fadd_f32(obase + (int64_t)cur * ldo, acc);
+          if (cur >= 0 && cok) __builtin_amdgcn_global_atomic_fadd_f32(obase + (int64_t)cur * ldo, acc);
         }
       } else if (vec) {
         constexpr uint32_t INV = (65536 + UPR - 1) / UPR;
@@ -457,7 +438,7 @@ __global__ __launch_bounds__(256, r16_waves_per_simd(NT2)) void tp_fwd_mfma_r16_
           float4 v = *reinterpret_cast<const float4*>(ot + __umul24(row, TS) + un * 4);
           const float* np = nbase + un * nstep;
           const float n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
-          if ((int)row < nrows && (int)lc0 < width && !(dbg & 1)) {
+          if ((int)row < nrows && (int)lc0 < width) {
             v.x *= n0; v.y *= n1; v.z *= n2; v.w *= n3;
             const uint32_t o = __umul24(row, ldo32) + (uint32_t)colb + lc0;
             if (IO16) {
@@ -480,7 +461,6 @@ __global__ __launch_bounds__(256, r16_waves_per_simd(NT2)) void tp_fwd_mfma_r16_
 #pragma unroll 1
           for (int r = 0; r < nrows; ++r) {
             const float v = src[r * TS] * nv;
-            if (dbg & 1) continue;
             if (IO16)
               reinterpret_cast<uint16_t*>(outv)[c0 + (int64_t)r * ldo] = __builtin_bit_cast(uint16_t, (__bf16)v);
             else
@@ -489,7 +469,6 @@ __global__ __launch_bounds__(256, r16_waves_per_simd(NT2)) void tp_fwd_mfma_r16_
         }
       }
       wave_sync_lds();
-      tick(5);
     };
     using I1 = std::integral_constant<int, 1>;
     using I3 = std::integral_constant<int, 3>;
@@ -534,10 +513,7 @@ __global__ __launch_bounds__(256, r16_waves_per_simd(NT2)) void tp_fwd_mfma_r16_
 #pragma unroll
       for (int t = 0; t < NT2; ++t) tile(I5{}, 2, t, [&](int q, int c) { return a2[2 * t + (q >> 2)][c][q & 3]; });
     }
-    tick(4);
   }
-  if (prof && lane == 0)
-    for (int q = 0; q < 8; ++q) atomicAdd(&prof[q], tacc[q]);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -573,55 +549,64 @@ static const std::vector<R16KernelEntry>& r16_kernels() {
   return k;
 }
 
-// E3_TP_R16: 0 = off, 1 (default) = fp32 storage only (measured: step 199.7 -> 184.4 ms against the two-wave kernel; for
-// bf16 storage the two-wave kernel is 1 % faster), 2 = both storage types
-static int r16_level() {
-  static const int lv = [] { const char* e = getenv("E3_TP_R16"); return e ? atoi(e) : 1; }();
-  return lv;
+static const R16KernelEntry* r16_find(const TpFast* F) {
+  const FDev& d = F->dev;
+  std::vector<int> l1s;
+  for (auto& c : F->h_chunks) {
+    l1s.push_back(c.l1);
+    if (c.count != 32 && c.count > 16) return nullptr;  // K = 32 steps: whole 32-channel chunks (or <= 16 channels: one dead half)
+  }
+  for (auto& k : r16_kernels())
+    if (k.lsh == d.lsh && k.nt0 == d.NT[0] && k.nt1 == d.NT[1] && k.nt2 == d.NT[2] && k.l1s == l1s) return &k;
+  return nullptr;
+}
+static size_t r16_lds_bytes(const TpFast* F, int nwaves) {
+  const FDev& d = F->dev;
+  const size_t tables = (size_t)(((d.Dout + 4 + 15) & ~15) + ((d.ntab + 15) & ~15)) * 4;
+  int lin = 0;
+  for (auto& c : F->h_chunks) lin = std::max(lin, c.l1);
+  const size_t per_wave = (size_t)(r16_chunk(lin, d.NT[2] > 0 ? 2 : (d.NT[1] > 0 ? 1 : 0)) + 160) * 4;
+  return tables + nwaves * per_wave;
+}
+constexpr int kR16Waves = 4;  // per workgroup; two or three workgroups per CU
+
+bool r16_supported(const TpFast* F) {
+  return r16_find(F) != nullptr &&
+         (size_t)r16_waves_per_simd(F->dev.NT[2]) * r16_lds_bytes(F, kR16Waves) <= (size_t)kFastLds;
 }
 
 // 1 = launched, 0 = not applicable, < 0 = -status
 int fast_forward_r16(const TpFast* F, const void* sa_, const void* in2, int64_t ld2, const void* packed, void* out,
-                     int64_t ldo, int64_t B, int gate, int mode, const int32_t* ocol_tab, hipStream_t s) {
+                     int64_t ldo, int64_t B, int gate, int io16, const int32_t* ocol_tab, const float* in_scale,
+                     hipStream_t s) {
   const bool scat = static_cast<const SegArgs*>(sa_)->scatter != nullptr;
-  if (mode < 1 || r16_level() < (mode == 2 ? 2 : 1)) return 0;
-  const FDev& d = mode == 2 ? F->dev16 : F->dev;
-  std::vector<int> l1s;
-  for (auto& c : F->h_chunks) {
-    l1s.push_back(c.l1);
-    if (c.count != 32 && c.count > 16) return 0;  // K = 32 steps: whole 32-channel chunks (or <= 16 channels: one dead half)
-  }
-  const R16KernelEntry* e = nullptr;
-  for (auto& k : r16_kernels())
-    if (k.lsh == d.lsh && k.nt0 == d.NT[0] && k.nt1 == d.NT[1] && k.nt2 == d.NT[2] && k.l1s == l1s) e = &k;
+  const FDev& d = F->dev;
+  const R16KernelEntry* e = r16_find(F);
   if (!e) return 0;
-  {  // diagnostic: E3_R16_MASK bit i disables table entry i
-    static const int mask = [] { const char* m = getenv("E3_R16_MASK"); return m ? atoi(m) : 0; }();
-    if (mask & (1 << (int)(e - r16_kernels().data()))) return 0;
-  }
-  if (scat && (mode != 1 || !gate || !e->fn_scat)) return 0;
-  const void* fn = scat ? e->fn_scat : e->fn[mode - 1][gate ? 1 : 0];
-  const size_t tables = (size_t)(((d.Dout + 4 + 15) & ~15) + ((d.ntab + 15) & ~15)) * 4;
-  int lin = 0;
-  for (int l : l1s) lin = std::max(lin, l);
-  const size_t per_wave = (size_t)(r16_chunk(lin, d.NT[2] > 0 ? 2 : (d.NT[1] > 0 ? 1 : 0)) + 160) * 4;
-  const int nwaves = 4;  // per workgroup; two workgroups per CU
-  const size_t lds_bytes = tables + nwaves * per_wave;
+  if (scat && (io16 || !gate || !e->fn_scat)) return 0;
+  const void* fn = scat ? e->fn_scat : e->fn[io16 ? 1 : 0][gate ? 1 : 0];
+  const size_t lds_bytes = r16_lds_bytes(F, kR16Waves);
   if ((size_t)r16_waves_per_simd(d.NT[2]) * lds_bytes > (size_t)kFastLds) return 0;
-  static std::vector<const void*> configured;
-  if (std::find(configured.begin(), configured.end(), fn) == configured.end()) {
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return -E3_ERR_HIP;
-    configured.push_back(fn);
+  {  // the dynamic-LDS limit is a per-device attribute of the function
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -E3_ERR_HIP;
+    static std::mutex mu;
+    static std::vector<std::pair<const void*, int>> configured;
+    std::lock_guard<std::mutex> lock(mu);
+    if (std::find(configured.begin(), configured.end(), std::make_pair(fn, dev)) == configured.end()) {
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return -E3_ERR_HIP;
+      configured.emplace_back(fn, dev);
+    }
   }
   const int64_t ntiles = (B + 15) / 16;
-  const int grid = (int)std::min<int64_t>((ntiles + nwaves - 1) / nwaves, 256 * r16_waves_per_simd(d.NT[2]));
+  const int grid = (int)std::min<int64_t>((ntiles + kR16Waves - 1) / kR16Waves, 256 * r16_waves_per_simd(d.NT[2]));
   const float* in2f = (const float*)in2;
   const float* pk = (const float*)packed;
   void* outf = out;
-  const FDev* dd = mode == 2 ? F->d_dev16 : F->d_dev;
+  const FDev* dd = F->d_dev;
   const FChunk* dc = F->d_chunks;
-  void* args[] = {const_cast<void*>(sa_), &in2f, &ld2, &pk, &outf, &ldo, &B, &dd, &dc, &ocol_tab};
-  if (hipLaunchKernel(fn, dim3(grid), dim3(64 * nwaves), args, lds_bytes, s) != hipSuccess) return -E3_ERR_HIP;
+  void* args[] = {const_cast<void*>(sa_), &in2f, &ld2, &pk, &outf, &ldo, &B, &dd, &dc, &ocol_tab, &in_scale};
+  if (hipLaunchKernel(fn, dim3(grid), dim3(64 * kR16Waves), args, lds_bytes, s) != hipSuccess) return -E3_ERR_HIP;
   fast_note_kernel("e3::tp_fwd_mfma_r16_kernel");
   return 1;
 }

@@ -206,6 +206,8 @@ def as_blocks(irreps) -> List[Tuple[int, int, int]]:
     """``[(l, p, mul), ...]`` for our :class:`Irreps`, a string, or a real ``e3nn.o3.Irreps``."""
     if isinstance(irreps, str):
         irreps = Irreps(irreps)
+    if isinstance(irreps, (list, tuple)) and all(isinstance(b, (list, tuple)) and len(b) == 3 for b in irreps):
+        return [(int(l), int(p), int(mul)) for l, p, mul in irreps]  # already blocks
     return [(int(m.ir.l), int(m.ir.p), int(m.mul)) for m in irreps]
 
 

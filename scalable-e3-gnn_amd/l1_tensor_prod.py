@@ -44,25 +44,10 @@ def _class_masks(irreps) -> dict:
     return masks
 
 
-class _Plan:
-    """Owns one ``e3_l1tp_plan*``."""
-
-    def __init__(self, in1_blocks, out_blocks):
-        lib = _lib.load()
-        a, na = _lib.blocks_array(in1_blocks)
-        b, nb = _lib.blocks_array(out_blocks)
-        handle = ctypes.c_void_p()
-        _lib.check(lib.e3_l1tp_plan_create(a, na, b, nb, ctypes.byref(handle)), "e3_l1tp_plan_create")
-        self.handle = handle
-        self._destroy = lib.e3_l1tp_plan_destroy
-
-    def __del__(self):
-        try:
-            if self.handle:
-                self._destroy(self.handle)
-                self.handle = None
-        except Exception:
-            pass
+def _Plan(in1_blocks, out_blocks) -> "_lib.DevicePlans":
+    """Per-device ``e3_l1tp_plan*`` handles (deep-copy / pickle safe)."""
+    return _lib.DevicePlans("e3_l1tp_plan_create", "e3_l1tp_plan_destroy", [tuple(b) for b in in1_blocks],
+                            [tuple(b) for b in out_blocks])
 
 
 class _L1TPFunction(torch.autograd.Function):
@@ -228,7 +213,7 @@ class L1TensorProduct(Module):
     def _norms(self) -> List[Optional[Tensor]]:
         return [getattr(self, "norm_" + c, None) for c in _CLS]
 
-    def _get_plan(self) -> _Plan:
+    def _get_plan(self):
         if self._plan is None:
             self._plan = _Plan(as_blocks(self.iri1), as_blocks(self.iro))
         return self._plan
@@ -247,12 +232,12 @@ class L1TensorProduct(Module):
                     f"L1TensorProduct: parameter/buffer dtype/device {t.dtype}/{t.device} does not match "
                     f"input {dtype}/{device} (cast the module, autocast is not supported — as in the reference)")
         plan = self._get_plan()
-        nbytes = lib.e3_l1tp_packed_bytes(plan.handle, code)
+        nbytes = lib.e3_l1tp_packed_bytes(plan.handle(device), code)
         packed = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
         wsc = [w.detach().contiguous() if w is not None else None for w in ws]
         nsc = [n.detach().contiguous() if n is not None else None for n in ns]
         stream = torch.cuda.current_stream(device).cuda_stream
-        _lib.check(lib.e3_l1tp_pack_weights(plan.handle, _lib.ptr4(wsc), _lib.ptr4(nsc), code,
+        _lib.check(lib.e3_l1tp_pack_weights(plan.handle(device), _lib.ptr4(wsc), _lib.ptr4(nsc), code,
                                             packed.data_ptr(), stream), "e3_l1tp_pack_weights")
         self._packed, self._packed_key = packed, key
         return packed
@@ -272,7 +257,7 @@ class L1TensorProduct(Module):
             packed = self._packed_weights(in1.dtype, in1.device)
             stream = torch.cuda.current_stream(in1.device).cuda_stream
             t0 = profiling.begin() if profiling.enabled() else None
-            _lib.check(lib.e3_l1tp_forward(self._get_plan().handle, in1.data_ptr(), in1.stride(0),
+            _lib.check(lib.e3_l1tp_forward(self._get_plan().handle(in1.device), in1.data_ptr(), in1.stride(0),
                                            in2.data_ptr(), ld2, packed.data_ptr(), out.data_ptr(), out.stride(0),
                                            B, _lib.dtype_code(in1.dtype), int(self.kernel), stream),
                        "e3_l1tp_forward")
@@ -306,13 +291,13 @@ class L1TensorProduct(Module):
         code = _lib.dtype_code(dtype)
         with torch.cuda.device(device):
             plan = self._get_plan()
-            wbytes = lib.e3_l1tp_backward_workspace_bytes(plan.handle, B, code)
+            wbytes = lib.e3_l1tp_backward_workspace_bytes(plan.handle(device), B, code)
             work = torch.empty(max(int(wbytes), 16), dtype=torch.uint8, device=device)
             wsc = [w.detach().contiguous() if w is not None else None for w in ws]
             nsc = [n.detach().contiguous() if n is not None else None for n in ns]
             stream = torch.cuda.current_stream(device).cuda_stream
             _lib.check(lib.e3_l1tp_backward(
-                plan.handle, in1.data_ptr(), in1.stride(0), in2.data_ptr(), ld2,
+                plan.handle(device), in1.data_ptr(), in1.stride(0), in2.data_ptr(), ld2,
                 _lib.ptr4(wsc), _lib.ptr4(nsc), grad_out.data_ptr(), grad_out.stride(0),
                 g_in1.data_ptr() if g_in1 is not None else None, g_in1.stride(0) if g_in1 is not None else 0,
                 g_in2.data_ptr() if g_in2 is not None else None,
@@ -331,13 +316,13 @@ class L1TensorProduct(Module):
     def fused_supported(self, gate: bool) -> bool:
         return self._fused_plan().fused_supported(gate)
 
-    def forward_fused(self, segments, in2: Tensor, gate: bool = False, scatter=None):
+    def forward_fused(self, segments, in2: Tensor, gate: bool = False, scatter=None, in_scale=None):
         """``scatter=(row_node, n_nodes)``: fused segment-sum (see ``TPPlan.forward_fused``); returns None when the
         library has no such kernel for this product (callers then run the two kernels)."""
         ws = self._weights() + [None, None]
         ns = self._norms() + [None, None]
         return self._fused_plan().forward_fused(ws, ns, segments, in2, gate, tag=f"{self.iri1}->{self.iro}",
-                                                scatter=scatter)
+                                                scatter=scatter, in_scale=in_scale)
 
     # ------------------------------------------------------------------------------------------
     def forward(self, in1: Tensor, in2: Tensor) -> Tensor:

@@ -107,3 +107,48 @@ def gate_blocks(x: torch.Tensor, ns: int, blocks) -> torch.Tensor:
         _lib.check(_lib.load().e3_gate_blocks(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), B, ns,
                                               len(blocks), ls, ms, _stream(x)), "e3_gate_blocks")
     return out
+
+
+def pow2_scale(tensors, target_log2: int = 10) -> torch.Tensor:
+    """Device-resident operand scale ``[s, 1/s, scratch, scratch]`` (fp32) of up to 4 fp32 tensors: ``s`` is the power of
+    two that puts their joint max |x| at ``2^target_log2`` (``e3_pow2_scale``; no host sync).  The fp16-split MFMA
+    kernels take it as ``in_scale``."""
+    import ctypes
+    from .tensor_product import TPSegment
+    ts = []
+    for t in tensors:
+        _check(t, "pow2_scale")
+        if t.dim() == 1:
+            t = t.unsqueeze(1)
+        if t.stride(-1) != 1:
+            t = t.contiguous()
+        ts.append(t)
+    assert 1 <= len(ts) <= 4
+    dev = ts[0].device
+    out = torch.empty(4, dtype=torch.float32, device=dev)
+    segs = (TPSegment * len(ts))()
+    rows = (ctypes.c_int64 * len(ts))()
+    for i, t in enumerate(ts):
+        segs[i].base, segs[i].ld, segs[i].ncols = t.data_ptr(), t.stride(0), t.shape[1]
+        rows[i] = t.shape[0]
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().e3_pow2_scale(ctypes.byref(segs), rows, len(ts), target_log2, out.data_ptr(),
+                                             _stream(out)), "e3_pow2_scale")
+    return out
+
+
+def add_pow2_scale(h: torch.Tensor, u: torch.Tensor, target_log2: int = 10):
+    """``h + u`` and the operand scale of the sum in one pass (``e3_add_pow2_scale``) -> (sum, scale)."""
+    _check(h, "h")
+    _check(u, "u")
+    assert h.shape == u.shape
+    h, u = h.contiguous(), u.contiguous()
+    out = torch.empty_like(h)
+    sc = torch.empty(4, dtype=torch.float32, device=h.device)
+    if h.numel() % 4 or (h.data_ptr() | u.data_ptr() | out.data_ptr()) % 16:
+        torch.add(h, u, out=out)
+        return out, pow2_scale([out], target_log2)
+    with torch.cuda.device(h.device):
+        _lib.check(_lib.load().e3_add_pow2_scale(h.data_ptr(), u.data_ptr(), out.data_ptr(), h.numel(), target_log2,
+                                                 sc.data_ptr(), _stream(h)), "e3_add_pow2_scale")
+    return out, sc

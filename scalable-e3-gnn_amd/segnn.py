@@ -19,8 +19,6 @@ Every TP is the reference operator (`L1TensorProduct`), i.e. the pinned hot path
 """
 from __future__ import annotations
 
-import os
-
 import torch
 from torch import nn
 
@@ -49,9 +47,9 @@ class SEGNNLayer(nn.Module):
         super().__init__()
         hid, gated = _hidden_irreps(H, lmax)
         self.H, self.lmax = H, lmax
-        self.fused = True  # use the fused gather+TP+gate kernel when the shapes allow it
-        # fused segment-sum (atomics: sums agree to fp32 rounding, not bit for bit); E3_FUSED_SCATTER=0 disables
-        self.fuse_scatter = os.environ.get("E3_FUSED_SCATTER", "1") != "0"
+        self.fused = True           # fused gather + TP + gate (+ segment-sum) kernels when the shapes allow it
+        self.fuse_scatter = True    # segment-sum by fp32 atomics in the message kernel (sums agree to fp32 rounding, not
+        #                             bit for bit); False = separate, bitwise reproducible e3_segment_sum
         self.msg1 = _make_tp(hid + hid + Irreps("1x0e"), gated, lmax)
         self.msg2 = _make_tp(hid, gated, lmax)
         self.upd1 = _make_tp(hid + hid, gated, lmax)
@@ -61,23 +59,27 @@ class SEGNNLayer(nn.Module):
         H = self.H
         return ops.gate(t, H, H) if self.lmax == 1 else ops.gate_blocks(t, H, [(1, H), (2, H)])
 
-    def _fused(self) -> bool:
+    def fused_available(self) -> bool:
+        """Static part only (shapes with an MFMA instantiation); grad mode is looked at on every call."""
         f = getattr(self, "_fused_ok", None)
         if f is None:
-            f = (self.H == 32 and not torch.is_grad_enabled() and
-                 all(tp.fused_supported(True) for tp in (self.msg1, self.msg2, self.upd1)))
-            self._fused_ok = f
-        return f and not torch.is_grad_enabled()
+            f = self._fused_ok = all(tp.fused_supported(True) for tp in (self.msg1, self.msg2, self.upd1))
+        return f
 
-    def forward(self, h, g: RadiusGraph, Y, d, A):
-        if h.dtype == torch.bfloat16 and not (self.fused and self._fused()):
-            raise RuntimeError("bf16 storage needs the fused MFMA path (H = 32, torch.no_grad())")
-        if self.fused and self._fused():
+    def forward(self, h, g: RadiusGraph, Y, d, A, h_scale=None):
+        """-> (h_next, operand scale of h_next | None)"""
+        use_fused = self.fused and self.fused_available() and not (torch.is_grad_enabled() and _needs_grad(self, h))
+        if h.dtype == torch.bfloat16 and not use_fused:
+            raise RuntimeError("bf16 storage needs the fused MFMA path (inference, shapes with an MFMA instantiation)")
+        if use_fused:
             # gather + concat + TP + gate in one kernel each: no [E, 2D+1] / raw-TP tensors in HBM
             if d.dtype != h.dtype:
                 d = d.to(h.dtype)
-            m = self.msg1.forward_fused([(h, g.dst), (h, g.src), (d, None)], Y, gate=True)
-            # message TP #2 with the segment-sum fused into its epilogue where the library has that kernel (l_max = 2): the [E, width] messages are never written; otherwise two kernels
+            f32 = h.dtype == torch.float32
+            sc1 = ops.pow2_scale([h, d]) if f32 else None
+            m = self.msg1.forward_fused([(h, g.dst), (h, g.src), (d, None)], Y, gate=True, in_scale=sc1)
+            # message TP #2 with the segment-sum fused into its epilogue where the library has that kernel: the
+            # [E, width] messages are never written; otherwise two kernels
             a = None
             if self.fuse_scatter:
                 a = self.msg2.forward_fused([(m, None)], Y, gate=True, scatter=(g.dst, g.rowptr.numel() - 1))
@@ -86,14 +88,20 @@ class SEGNNLayer(nn.Module):
                 a = ops.segment_sum(m, g)
             u = self.upd1.forward_fused([(h, None), (a, None)], A, gate=True)
             u = self.upd2(u, A)
-            return h + u
+            if f32:
+                return ops.add_pow2_scale(h, u)
+            return h + u, None
         m = ops.gather_concat(h, g, d)
         m = self._gate(self.msg1(m, Y))
         m = self._gate(self.msg2(m, Y))
         a = ops.segment_sum(m, g)
         u = self._gate(self.upd1(torch.cat([h, a], 1), A))
         u = self.upd2(u, A)
-        return h + u
+        return h + u, None
+
+
+def _needs_grad(mod: nn.Module, *tensors) -> bool:
+    return any(t.requires_grad for t in tensors) or any(p.requires_grad for p in mod.parameters())
 
 
 class SEGNN(nn.Module):
@@ -117,8 +125,10 @@ class SEGNN(nn.Module):
         if x.dtype == torch.bfloat16 and self.lmax != 2:
             raise RuntimeError("bf16 storage is implemented for l_max = 2 (BASELINE config 3)")
         h = self.embed(x, A)
+        sc = None
         for layer in self.layers:
             if halo is not None:
                 h = halo.exchange(h)
-            h = layer(h, g, Y, d, A)
+                sc = None  # ghost rows changed
+            h, sc = layer(h, g, Y, d, A, sc)
         return self.readout(h, A)

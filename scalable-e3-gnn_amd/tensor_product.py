@@ -9,7 +9,6 @@ Forward only (fp32 / fp64), ROCm tensors only, no CPU path.
 from __future__ import annotations
 
 import ctypes
-import os
 from math import sqrt
 
 import torch
@@ -27,21 +26,19 @@ class TPSegment(ctypes.Structure):
 
 
 class TPPlan:
-    """One ``e3_tp_plan*`` plus its packed-weight cache; shared by ``SHTensorProduct`` and by
-    ``L1TensorProduct.forward_fused`` (the l <= 1 operator is the lmax_sh = 1 special case)."""
+    """``e3_tp_plan*`` handles (one per device) plus the packed-weight cache; shared by ``SHTensorProduct`` and by
+    ``L1TensorProduct.forward_fused`` (the l <= 1 operator is the lmax_sh = 1 special case).  Deep-copy / pickle safe:
+    only the irreps blocks are state."""
 
     def __init__(self, in1_irreps, out_irreps, lmax_sh):
         lib = _lib.load()
-        a, na = _lib.blocks_array(as_blocks(in1_irreps))
-        b, nb = _lib.blocks_array(as_blocks(out_irreps))
-        self.handle = ctypes.c_void_p()
-        _lib.check(lib.e3_tp_plan_create(a, na, lmax_sh, b, nb, ctypes.byref(self.handle)), "e3_tp_plan_create")
-        self._destroy = lib.e3_tp_plan_destroy
-        self.in1_dim = lib.e3_tp_in1_dim(self.handle)
-        self.in2_dim = lib.e3_tp_in2_dim(self.handle)
-        self.out_dim = lib.e3_tp_out_dim(self.handle)
-        self._packed = None
-        self._key = None
+        self._blocks = ([tuple(b) for b in as_blocks(in1_irreps)], int(lmax_sh), [tuple(b) for b in as_blocks(out_irreps)])
+        self._plans = _lib.DevicePlans("e3_tp_plan_create", "e3_tp_plan_destroy", *self._blocks)
+        h = self._plans.handle(None)
+        self.in1_dim = lib.e3_tp_in1_dim(h)
+        self.in2_dim = lib.e3_tp_in2_dim(h)
+        self.out_dim = lib.e3_tp_out_dim(h)
+        self._packed = {}
         # algorithmic flops per row: sum over paths of 2 K M min(2 l1+1, 2 l3+1) (the contraction with W; the
         # per-row CG/feature algebra is excluded, as in SURVEY.md §8d)
         n, M = {}, {}
@@ -57,45 +54,66 @@ class TPPlan:
                         fl += 2 * k * m3 * min(2 * l1 + 1, 2 * l3 + 1)
         self.flops_per_row = fl
 
-    def __del__(self):
-        try:
-            if self.handle:
-                self._destroy(self.handle)
-                self.handle = None
-        except Exception:
-            pass
+    def __deepcopy__(self, memo):
+        return _rebuild_tpplan(*self._blocks)
+
+    def __reduce__(self):
+        return (_rebuild_tpplan, self._blocks)
+
+    def handle(self, device=None):
+        return self._plans.handle(device)
+
+    def weight_shape(self, ci):
+        rows, cols = ctypes.c_int(), ctypes.c_int()
+        _lib.load().e3_tp_weight_shape(self.handle(), ci, ctypes.byref(rows), ctypes.byref(cols))
+        return rows.value, cols.value
+
+    def norm_len(self, ci):
+        return _lib.load().e3_tp_norm_len(self.handle(), ci)
 
     def fused_supported(self, gate: bool) -> bool:
-        return bool(_lib.load().e3_tp_fused_supported(self.handle, 1 if gate else 0))
+        return bool(_lib.load().e3_tp_fused_supported(self.handle(), 1 if gate else 0))
 
     def packed(self, ws, ns, dtype, device):
-        """ws / ns: 6-entry lists (per class) of optional tensors."""
+        """ws / ns: 6-entry lists (per class) of optional tensors.  The packed buffer is rebuilt when a parameter or
+        buffer was replaced or modified through autograd-visible ops (``_version``); in-place edits through ``.data``
+        do not bump the version counter -- call ``invalidate_packed()`` after those."""
         key = (dtype, device) + tuple((t.data_ptr(), t._version) if t is not None else None for t in ws + ns)
-        if self._packed is not None and self._key == key:
-            return self._packed
+        hit = self._packed.get((dtype, device))
+        stream = torch.cuda.current_stream(device)
+        if hit is not None and hit[0] == key:
+            if hit[2] != stream.cuda_stream:
+                stream.wait_event(hit[3])  # packed on another stream: order this stream behind the pack kernels
+            return hit[1]
         lib = _lib.load()
         code = _lib.dtype_code(dtype)
         for t in ws + ns:
             if t is not None and t.numel() and (t.dtype != dtype or t.device != device):
                 raise RuntimeError(f"tensor product: parameter {t.dtype}/{t.device} vs input {dtype}/{device}")
-        nbytes = lib.e3_tp_packed_bytes(self.handle, code)
+        h = self.handle(device)
+        nbytes = lib.e3_tp_packed_bytes(h, code)
         if nbytes < 0:
-            raise RuntimeError(f"tensor product supports float32/float64, got {dtype}")
+            raise RuntimeError(f"tensor product supports float32/float64/bfloat16, got {dtype}")
         packed = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
         P6 = ctypes.c_void_p * 6
         ptr = lambda t: t.data_ptr() if (t is not None and t.numel()) else None
         wsc = [w.detach().contiguous() if w is not None else None for w in ws]
         nsc = [n.detach().contiguous() if n is not None else None for n in ns]
-        stream = torch.cuda.current_stream(device).cuda_stream
-        _lib.check(lib.e3_tp_pack_weights(self.handle, P6(*map(ptr, wsc)), P6(*map(ptr, nsc)), code,
-                                          packed.data_ptr(), stream), "e3_tp_pack_weights")
-        self._packed, self._key = packed, key
+        _lib.check(lib.e3_tp_pack_weights(h, P6(*map(ptr, wsc)), P6(*map(ptr, nsc)), code,
+                                          packed.data_ptr(), stream.cuda_stream), "e3_tp_pack_weights")
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        self._packed[(dtype, device)] = (key, packed, stream.cuda_stream, ev)
         return packed
 
-    def forward_fused(self, ws, ns, segments, in2, gate: bool, tag="", scatter=None):
-        """segments: [(tensor [R, ncols] fp32, row_index int32 [B] | None), ...]; -> [B, out_dim or gated width].
+    def invalidate_packed(self):
+        self._packed = {}
+
+    def forward_fused(self, ws, ns, segments, in2, gate: bool, tag="", scatter=None, in_scale=None):
+        """segments: [(tensor [R, ncols], row_index int32 [B] | None), ...]; -> [B, out_dim or gated width].
         scatter = (row_node int32 [B] ascending, n_nodes): rows are summed per node instead of stored (fused
-        segment-sum, fp32 atomics) -> [n_nodes, width]; returns None when the library has no such kernel for this plan."""
+        segment-sum, fp32 atomics) -> [n_nodes, width]; returns None when the library has no such kernel for this plan.
+        in_scale: power-of-two operand scale of the segments (``ops.pow2_scale``); computed here when None (fp32)."""
         lib = _lib.load()
         B = in2.shape[0]
         dev = in2.device
@@ -122,7 +140,6 @@ class TPPlan:
                 assert t.shape[0] == B
         width = self.out_dim
         if gate:
-            ngated = (self.out_dim - 32) // 4 if self.out_dim in (160, ) else None
             width = {160: 128, 352: 288, 224: 192}.get(self.out_dim)
             if width is None:
                 raise RuntimeError("gate fusion needs out irreps [32x0e | 32x0e per block | 32x1o | 32x2e]")
@@ -141,31 +158,39 @@ class TPPlan:
         esz = out.element_size()
         with torch.cuda.device(dev):
             packed = self.packed(ws, ns, io, dev)
+            if io == torch.float32 and in_scale is None:
+                from . import ops
+                in_scale = ops.pow2_scale(keep)
+            sc = in_scale.data_ptr() if (in_scale is not None and io == torch.float32) else None
             stream = torch.cuda.current_stream(dev).cuda_stream
             t0 = profiling.begin() if profiling.enabled() else None
+            h = self.handle(dev)
             if scatter is not None:
-                st = lib.e3_tp_forward_fused_scatter(self.handle, ctypes.byref(segs), len(segments), in2.data_ptr(),
+                st = lib.e3_tp_forward_fused_scatter(h, ctypes.byref(segs), len(segments), in2.data_ptr(),
                                                      in2.stride(0), packed.data_ptr(), scatter[0].data_ptr(),
-                                                     out.data_ptr(), out.stride(0), B, _lib.dtype_code(io), 1, stream)
+                                                     out.data_ptr(), out.stride(0), B, _lib.dtype_code(io), 1, sc, stream)
                 if st == 4:  # E3_ERR_UNSUPPORTED: no fused-scatter kernel for this plan / build
                     return None
                 _lib.check(st, "e3_tp_forward_fused_scatter")
                 if io != torch.float32:
                     out = out.to(io)  # one rounding of the fp32 sums (what e3_segment_sum_bf16 does)
             else:
-                _lib.check(lib.e3_tp_forward_fused(self.handle, ctypes.byref(segs), len(segments), in2.data_ptr(),
+                _lib.check(lib.e3_tp_forward_fused(h, ctypes.byref(segs), len(segments), in2.data_ptr(),
                                                    in2.stride(0), packed.data_ptr(), out.data_ptr(), out.stride(0), B,
-                                                   _lib.dtype_code(io), 1 if gate else 0, stream), "e3_tp_forward_fused")
+                                                   _lib.dtype_code(io), 1 if gate else 0, sc, stream), "e3_tp_forward_fused")
             if t0 is not None:
                 # algorithmic bytes: gathered segments count their SOURCE rows once (re-gathers are cache traffic)
                 nb = sum((t.shape[0] * t.shape[1] * esz + (4 * B if idx is not None else 0)) for t, idx in
                          [(k, s[1]) for k, s in zip(keep, segments)]) + 4 * self.in2_dim * B + \
                      (esz * width * B if scatter is None else 4 * B + 4 * width * scatter[1])
-                mode = ("<bf16 storage, bf16 MFMA>" if io == torch.bfloat16 else
-                        "<exact fp32 MFMA>" if os.environ.get("E3_TP_EXACT") else "<bf16x3 split MFMA>")
+                mode = "<bf16 storage, bf16 MFMA>" if io == torch.bfloat16 else "<fp16x3 split MFMA>"
                 profiling.end(f"tp_fused{'+segsum' if scatter is not None else ''} {tag} B={B}", B, nb, t0, flops=self.flops_per_row * B,
-                              kernel=(lib.e3_tp_last_fused_kernel() or b"e3::tp_fwd_mfma_kernel").decode() + mode)
+                              kernel=(lib.e3_tp_last_fused_kernel() or b"e3::tp_fwd_mfma_r16_kernel").decode() + mode)
         return out
+
+
+def _rebuild_tpplan(in_blocks, lmax_sh, out_blocks):
+    return TPPlan(in_blocks, out_blocks, lmax_sh)
 
 
 class _SHTPFunction(torch.autograd.Function):
@@ -207,7 +232,7 @@ class _SHTPFunction(torch.autograd.Function):
             with torch.cuda.device(in1.device):
                 packed = mod._packed_weights(in1.dtype, in1.device)
                 stream = torch.cuda.current_stream(in1.device).cuda_stream
-                _lib.check(lib.e3_tp_backward(mod._handle, in1.data_ptr(), in1.stride(0), in2.data_ptr(),
+                _lib.check(lib.e3_tp_backward(mod._plan.handle(in1.device), in1.data_ptr(), in1.stride(0), in2.data_ptr(),
                                               0 if bcast else in2.stride(0), packed.data_ptr(), grad_out.data_ptr(),
                                               grad_out.stride(0), g1.data_ptr() if g1 is not None else None,
                                               in1.stride(0) if g1 is not None else 0,
@@ -229,19 +254,19 @@ class SHTensorProduct(nn.Module):
         self.iro = Irreps(out_irreps) if isinstance(out_irreps, str) else out_irreps
         self.iri2 = Irreps.spherical_harmonics(lmax_sh)
         self.lmax_sh = lmax_sh
-        lib = _lib.load()
+        self.exact = False  # True: fp32 inputs run on the generic fp32 FMA kernel instead of the fp16-split MFMA kernel
         self._plan = TPPlan(self.iri1, self.iro, lmax_sh)
-        self._handle = self._plan.handle
         self.in1_dim, self.in2_dim, self.out_dim = self._plan.in1_dim, self._plan.in2_dim, self._plan.out_dim
         for ci, c in enumerate(CLASSES):
-            rows, cols = ctypes.c_int(), ctypes.c_int()
-            lib.e3_tp_weight_shape(self._handle, ci, ctypes.byref(rows), ctypes.byref(cols))
-            nlen = lib.e3_tp_norm_len(self._handle, ci)
-            if rows.value > 0 and cols.value > 0:
-                setattr(self, "weights_" + c, nn.Parameter(torch.rand((rows.value, cols.value)) * 2 - 1))
+            rows, cols = self._plan.weight_shape(ci)
+            nlen = self._plan.norm_len(ci)
+            if rows > 0 and cols > 0:
+                setattr(self, "weights_" + c, nn.Parameter(torch.rand((rows, cols)) * 2 - 1))
             l = ci >> 1
-            val = sqrt((2 * l + 1) / rows.value) if rows.value > 0 else 1.0
+            val = sqrt((2 * l + 1) / rows) if rows > 0 else 1.0
             self.register_buffer("norm_" + c, torch.full((nlen,), val))
+
+
     def _tensors(self):
         ws = [getattr(self, "weights_" + c, None) for c in CLASSES]
         ns = [getattr(self, "norm_" + c) for c in CLASSES]
@@ -254,11 +279,12 @@ class SHTensorProduct(nn.Module):
     def fused_supported(self, gate: bool) -> bool:
         return self._plan.fused_supported(gate)
 
-    def forward_fused(self, segments, in2, gate: bool = False, scatter=None):
+    def forward_fused(self, segments, in2, gate: bool = False, scatter=None, in_scale=None):
         """TP over ``in1 = [seg0[idx0] | seg1[idx1] | ...]`` (gather + concat fused), optional fused gate, optional
         fused segment-sum (``scatter=(row_node, n_nodes)``, see ``TPPlan.forward_fused``; None = unsupported)."""
         ws, ns = self._tensors()
-        return self._plan.forward_fused(ws, ns, segments, in2, gate, tag=f"{self.iri1}->{self.iro}", scatter=scatter)
+        return self._plan.forward_fused(ws, ns, segments, in2, gate, tag=f"{self.iri1}->{self.iro}", scatter=scatter,
+                                        in_scale=in_scale)
 
     def forward(self, in1: torch.Tensor, in2: torch.Tensor) -> torch.Tensor:
         torch._assert(in1.shape[-1] == self.in1_dim,
@@ -279,7 +305,7 @@ class SHTensorProduct(nn.Module):
             return _SHTPFunction.apply(self, in1, in2, *ws)
         return self._forward_impl(in1, in2)
 
-    def _forward_impl(self, in1: torch.Tensor, in2: torch.Tensor) -> torch.Tensor:
+    def _forward_impl(self, in1: torch.Tensor, in2: torch.Tensor, in_scale=None) -> torch.Tensor:
         B = in1.shape[0]
         out = torch.empty((B, self.out_dim), dtype=in1.dtype, device=in1.device)
         if B == 0:
@@ -295,15 +321,20 @@ class SHTensorProduct(nn.Module):
         lib = _lib.load()
         with torch.cuda.device(in1.device):
             packed = self._packed_weights(in1.dtype, in1.device)
+            mfma = in1.dtype == torch.float32 and not self.exact and ld2 != 0 and self._plan.fused_supported(False)
+            if mfma and in_scale is None:
+                from . import ops
+                in_scale = ops.pow2_scale([in1])
             stream = torch.cuda.current_stream(in1.device).cuda_stream
             t0 = profiling.begin() if profiling.enabled() else None
-            _lib.check(lib.e3_tp_forward(self._handle, in1.data_ptr(), in1.stride(0), in2.data_ptr(), ld2,
+            _lib.check(lib.e3_tp_forward(self._plan.handle(in1.device), in1.data_ptr(), in1.stride(0), in2.data_ptr(), ld2,
                                          packed.data_ptr(), out.data_ptr(), out.stride(0), B,
-                                         _lib.dtype_code(in1.dtype), stream), "e3_tp_forward")
+                                         _lib.dtype_code(in1.dtype), in_scale.data_ptr() if (mfma and in_scale is not None) else None,
+                                         1 if self.exact else 0, stream), "e3_tp_forward")
             if t0 is not None:
                 profiling.end(f"tp_fwd(l<=2) {self.iri1}->{self.iro} B={B}", B,
                               in1.element_size() * (self.in1_dim + self.in2_dim + self.out_dim) * B, t0,
                               flops=self._plan.flops_per_row * B,
-                              kernel="e3::tp_fwd_mfma_kernel" if (in1.dtype != torch.float64 and
-                                                                   self._plan.fused_supported(False)) else "e3::tp_fwd_generic_kernel")
+                              kernel="e3::tp_fwd_mfma_r16_kernel" if (in1.dtype != torch.float64 and not self.exact and
+                                                                       self._plan.fused_supported(False)) else "e3::tp_fwd_generic_kernel")
         return out
