@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define E3GNN_ABI_VERSION 1
+#define E3GNN_ABI_VERSION 2
 
 /* status codes */
 enum {
@@ -268,6 +268,40 @@ int e3_tp_forward_fused_scatter(const e3_tp_plan* plan, const e3_tp_segment* seg
                                 const void* in2, int64_t ld_in2, const void* packed, const int32_t* row_node,
                                 void* out_nodes, int64_t ld_out, int64_t B, int dtype, int gate,
                                 const float* in_scale, void* stream);
+/* =================================================================================================
+ * Fused SEGNN message function (builder-defined; the north_star's "fused per-edge CDNA4 HIP kernel"):
+ *
+ *   out[i] = sum_{e: dst[e] = i} gate( TP2( gate( TP1( [h[dst[e]] | h[src[e]] | d_e] ; Y_e ) ) ; Y_e ) )
+ *
+ * with Y_e, d_e = component spherical harmonics (l <= lmax) and length of pos[src[e]] - pos[dst[e]] (the expressions of
+ * e3_edge_geometry / e3_edge_geometry_l2), TP1 / TP2 = e3_tp_* products with in irreps Hx0e+Hx1o(+Hx2e) (TP1: twice that
+ * plus 1x0e) and out irreps Hx0e + lmax*H x0e + Hx1o (+Hx2e), gate = [silu(s) | sigmoid(g_l) v_l].  One launch (plus a
+ * per-node pre-mix launch) per layer: neither Y [E, 9], d [E] nor any [E, width] message tensor exists in HBM.
+ * hidden in {16, 32, 64}; fp32 storage; fp16 (hi, lo)-split MFMA products (see "Operand scales"; `in_scale` = scale of
+ * h, NULL = 1; the gated messages between the two products are scaled per edge row inside the kernel).
+ * Edges must be sorted by dst (CSR order, as e3_rg_fill emits them): runs of equal dst are summed on chip and leave as
+ * one fp32 atomic add per node and wave -- sums agree with e3_segment_sum to fp32 rounding, not bit for bit.
+ *   weights: w1[l3] / w2[l3] = the class matrices of TP1 / TP2 for output degree l3 (0e, 1o, 2e), row order and shapes
+ *            as e3_tp_weight_shape reports for those irreps (e3_msg_weight_shape returns the same numbers);
+ *            n1 / n2 = their norm buffers (length M, 3 M, 5 M) or NULL for 1.
+ *   premix : workspace of N * e3_msg_premix_floats_per_node() floats (W_dst h per node, the dst half of TP1)
+ *   out    : [N, ld_out] fp32, columns [H | 3 H | 5 H]; zero-filled by the call unless accumulate != 0
+ *   accumulate != 0: a second edge list for the SAME h rows of the dst nodes (e.g. the halo's boundary edges after the
+ *            interior ones): out keeps its contents and `premix` must still hold the table the first call wrote
+ *   tiles_per_block: consecutive 16-edge tiles a wave processes before it jumps (0 = a quarter of its workgroup's range)
+ * One plan belongs to the device current at its first use.
+ * ================================================================================================= */
+typedef struct e3_msg_plan e3_msg_plan;
+int e3_msg_plan_create(int lmax, int hidden, e3_msg_plan** plan);
+int e3_msg_plan_destroy(e3_msg_plan* plan);
+int64_t e3_msg_packed_bytes(const e3_msg_plan* plan);
+int64_t e3_msg_premix_floats_per_node(const e3_msg_plan* plan);
+int e3_msg_weight_shape(const e3_msg_plan* plan, int tp /* 1 | 2 */, int l3, int* rows, int* cols);
+int e3_msg_pack_weights(e3_msg_plan* plan, const float* const w1[3], const float* const n1[3],
+                        const float* const w2[3], const float* const n2[3], void* packed, void* stream);
+int e3_msg_forward(e3_msg_plan* plan, const float* h, int64_t ld_h, int64_t N, const float* pos4,
+                   const int32_t* src, const int32_t* dst, int64_t E, const void* packed, const float* in_scale,
+                   float* premix, float* out, int64_t ld_out, int accumulate, int tiles_per_block, void* stream);
 /*
  * bf16 storage (dtype E3_BF16, BASELINE config 3): segments / in1 / out / weights / norms are bf16, in2 (the
  * spherical harmonics) stays fp32, products run once on v_mfma_f32_16x16x32_bf16 with fp32 accumulation and one

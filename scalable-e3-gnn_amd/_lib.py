@@ -61,6 +61,14 @@ SIGNATURES = {
                               c_int, c_void_p, c_int, c_void_p]),
     "e3_tp_forward_fused": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64,
                                     c_int, c_int, c_void_p, c_void_p]),
+    "e3_msg_plan_create": (c_int, [c_int, c_int, POINTER(c_void_p)]),
+    "e3_msg_plan_destroy": (c_int, [c_void_p]),
+    "e3_msg_packed_bytes": (c_int64, [c_void_p]),
+    "e3_msg_premix_floats_per_node": (c_int64, [c_void_p]),
+    "e3_msg_weight_shape": (c_int, [c_void_p, c_int, c_int, POINTER(c_int), POINTER(c_int)]),
+    "e3_msg_pack_weights": (c_int, [c_void_p, c_void_p * 3, c_void_p * 3, c_void_p * 3, c_void_p * 3, c_void_p, c_void_p]),
+    "e3_msg_forward": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
+                               c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "e3_pow2_scale": (c_int, [c_void_p, POINTER(c_int64), c_int, c_int, c_void_p, c_void_p]),
     "e3_add_pow2_scale": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "e3_tp_backward": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p,

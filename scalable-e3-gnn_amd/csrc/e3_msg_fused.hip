@@ -83,7 +83,8 @@ struct MsgGeom {
   static constexpr int blk_floats = 64 * 8;  // 64 lanes x (hi uint4 + lo uint4)
   static constexpr int64_t total_floats = (int64_t)o_w + 3LL * nblk() * blk_floats;
   static constexpr int lds_tab = 2 * NS * 16 + WD;  // floats of tables kept in LDS per workgroup
-  static constexpr int lds_wave = 16 * D;           // floats per wave: staged h[src] rows, later the parked messages
+  static constexpr int lds_wave = 16 * D + 16;      // floats per wave: staged h[src] rows, later the parked messages, then the
+                                                    // transposed tile with row stride D + 1
 };
 
 // k slot jj (0..7) of k group g inside a 32-channel K step  <->  channel: the accumulator layout of the previous product
@@ -238,124 +239,182 @@ __device__ __forceinline__ void load_w(const TpCtx& cx, const int blk, uint4& hi
   lo = uint4{l[0], l[1], l[2], l[3]};
 }
 
+// ---- one tensor product as a flat, software-pipelined list of blocks ----------------------------------------------
+// A block = one 16-channel output tile of one path: its weight operand(s) and (product #1) its 4 D1 pre-mix values are
+// fetched while the PREVIOUS block computes, so no block starts with an exposed L2 round trip.  Blocks are ordered by input
+// degree; the first block of a degree also loads that degree's inputs, builds the feature-first operand and the (hi, lo)
+// halves.  Everything is indexed at compile time (BlkList::at(IDX)); state that survives a block lives in TpState.
+struct BlkDesc {
+  int l1, l2, l3, t;
+  bool ff;             // feature-first path (scalar outputs from l1 > 0)
+  bool first_of_l1;    // load / split the inputs of degree l1 here
+  bool first_of_path;  // build z here
+};
+template <int LMAX, int TT>
+struct BlkList {
+  using G = MsgGeom<LMAX, TT>;
+  // order inside a degree: the feature-first path (needs the fp32 inputs), then the mix-first paths by (l3, l2)
+  static constexpr BlkDesc at(int idx) {
+    int n = 0;
+    for (int l1 = 0; l1 <= LMAX; ++l1) {
+      bool first = true;
+      for (int pass = 0; pass < 2; ++pass)
+        for (int l3 = 0; l3 <= LMAX; ++l3)
+          for (int l2 = 0; l2 <= LMAX; ++l2) {
+            if (!G::ok(l1, l2, l3)) continue;
+            const bool ff = l3 == 0 && l1 > 0;
+            if (ff != (pass == 0)) continue;
+            for (int t = 0; t < G::T(l3); ++t) {
+              if (n == idx) return BlkDesc{l1, l2, l3, t, ff, first, t == 0};
+              first = false;
+              ++n;
+            }
+          }
+    }
+    return BlkDesc{-1, 0, 0, 0, false, false, false};
+  }
+  static constexpr int count() {
+    int n = 0;
+    while (at(n).l1 >= 0) ++n;
+    return n;
+  }
+};
+
+template <int KS>
+struct TpState {
+  uint4 xh[KS][5], xl[KS][5];  // (hi, lo) halves of the current degree's inputs, per component
+  uint4 fh[KS], fl[KS];        // feature-first operand of the current degree
+  float z[5][5];               // coupling of the current path
+};
+
+template <int LMAX, int TT, bool FIRST, int IDX>
+__device__ __forceinline__ void tp_prefetch(const TpCtx& cx, uint4 (&wh)[MsgGeom<LMAX, TT>::KS],
+                                            uint4 (&wl)[MsgGeom<LMAX, TT>::KS], f32x4 (&uin)[5]) {
+  using G = MsgGeom<LMAX, TT>;
+  constexpr BlkDesc B = BlkList<LMAX, TT>::at(IDX);
+  constexpr int T = G::T(B.l3), B0 = G::blk(B.l1, B.l2, B.l3), U0 = G::uoff(B.l1, B.l2, B.l3);
+#pragma unroll
+  for (int ks = 0; ks < G::KS; ++ks) load_w(cx, B0 + ks * T + B.t, wh[ks], wl[ks]);
+  if constexpr (FIRST) {
+#pragma unroll
+    for (int a = 0; a < 2 * B.l1 + 1; ++a) uin[a] = *reinterpret_cast<const f32x4*>(cx.ud + U0 + (a * T + B.t) * 16);
+  }
+}
+
+template <int LMAX, int TT, bool FIRST, int IDX, class XLOAD>
+__device__ __forceinline__ void tp_block(const TpCtx& cx, const float (&y)[9], XLOAD& xload,
+                                         TpState<MsgGeom<LMAX, TT>::KS>& st, f32x4 (&acc0)[MsgGeom<LMAX, TT>::T(0)],
+                                         f32x4 (&acc1)[TT][3], f32x4 (&acc2)[LMAX == 2 ? TT : 1][5],
+                                         const uint4 (&wh)[MsgGeom<LMAX, TT>::KS], const uint4 (&wl)[MsgGeom<LMAX, TT>::KS],
+                                         const f32x4 (&uin)[5]) {
+  using G = MsgGeom<LMAX, TT>;
+  using BL = BlkList<LMAX, TT>;
+  constexpr int KS = G::KS;
+  constexpr BlkDesc B = BL::at(IDX);
+  constexpr int L1 = B.l1, L2 = B.l2, L3 = B.l3, t = B.t;
+  constexpr int D1 = 2 * L1 + 1, D3 = 2 * L3 + 1;
+  // ---- the next block's operands are requested first ----
+  uint4 nwh[KS], nwl[KS];
+  f32x4 nu[5];
+  if constexpr (IDX + 1 < BL::count()) tp_prefetch<LMAX, TT, FIRST, IDX + 1>(cx, nwh, nwl, nu);
+  // ---- first block of a degree: inputs, feature-first operand, (hi, lo) halves ----
+  if constexpr (B.first_of_l1) {
+    float x[KS][8][D1];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) xload(std::integral_constant<int, L1>{}, ks, x[ks]);
+    if constexpr (L1 > 0 && G::ok(L1, L1, 0)) {
+      float zz[D1][1];
+      make_z<L1, L1, 0>(y, zz);
+#pragma unroll
+      for (int a = 0; a < D1; ++a) st.z[a][0] = zz[a][0];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        float f[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          float sum = zz[0][0] * x[ks][i][0];
+#pragma unroll
+          for (int a = 1; a < D1; ++a) sum = __builtin_fmaf(zz[a][0], x[ks][i][a], sum);
+          f[i] = sum;
+        }
+        split8(f, st.fh[ks], st.fl[ks]);
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int a = 0; a < D1; ++a) {
+        float f[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = x[ks][i][a];
+        split8(f, st.xh[ks][a], st.xl[ks][a]);
+      }
+  }
+  if constexpr (B.first_of_path && !B.ff) {
+    float zz[D1][D3];
+    make_z<L1, L2, L3>(y, zz);
+#pragma unroll
+    for (int a = 0; a < D1; ++a)
+#pragma unroll
+      for (int c = 0; c < D3; ++c) st.z[a][c] = zz[a][c];
+  }
+  // ---- compute ----
+  if constexpr (B.ff) {
+    f32x4 o = acc0[t];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) o = mma3(wh[ks], wl[ks], st.fh[ks], st.fl[ks], o);
+    if constexpr (FIRST) {  // dst half: fold of the per-node pre-mix
+#pragma unroll
+      for (int a = 0; a < D1; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = __builtin_fmaf(uin[a][r], st.z[a][0], o[r]);
+    }
+    acc0[t] = o;
+  } else {
+    f32x4 u[D1];
+#pragma unroll
+    for (int a = 0; a < D1; ++a) {
+      if constexpr (FIRST) u[a] = uin[a];
+      else u[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if constexpr (FIRST && L1 == 0) {
+      const f32x4 wdv = *reinterpret_cast<const f32x4*>(cx.wd + G::wdoff(L3) + t * 16);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) u[0][r] = __builtin_fmaf(wdv[r], cx.dsc, u[0][r]);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int a = 0; a < D1; ++a) u[a] = mma3(wh[ks], wl[ks], st.xh[ks][a], st.xl[ks][a], u[a]);
+#pragma unroll
+    for (int c = 0; c < D3; ++c)
+#pragma unroll
+      for (int a = 0; a < D1; ++a)
+        if (z_nonzero<L1, L2, L3>(a, c)) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if constexpr (L3 == 0) acc0[t][r] = __builtin_fmaf(u[a][r], st.z[a][c], acc0[t][r]);
+            else if constexpr (L3 == 1) acc1[t][c][r] = __builtin_fmaf(u[a][r], st.z[a][c], acc1[t][c][r]);
+            else acc2[t][c][r] = __builtin_fmaf(u[a][r], st.z[a][c], acc2[t][c][r]);
+          }
+        }
+  }
+  if constexpr (IDX + 1 < BL::count())
+    tp_block<LMAX, TT, FIRST, IDX + 1>(cx, y, xload, st, acc0, acc1, acc2, nwh, nwl, nu);
+}
+
 // One tensor product on the lane's 16-edge tile.  XLOAD(l1tag, ks, x[8][D1]) delivers the (scaled) fp32 inputs of this
 // lane: x[jj][a] = channel 32 ks + kperm(g, jj), component a.  acc0 / acc1 / acc2: output tiles per degree.
-// Live registers are bounded by construction: per input degree the fp32 inputs exist only until the feature-first path
-// has run and the (hi, lo) halves are built; mix-first paths hold ONE temporary tile group u[a] at a time.
 template <int LMAX, int TT, bool FIRST, class XLOAD>
 __device__ __forceinline__ void tp_core(const TpCtx& cx, const float (&y)[9], XLOAD&& xload,
                                         f32x4 (&acc0)[MsgGeom<LMAX, TT>::T(0)], f32x4 (&acc1)[TT][3],
                                         f32x4 (&acc2)[LMAX == 2 ? TT : 1][5]) {
-  using G = MsgGeom<LMAX, TT>;
-  constexpr int KS = G::KS;
-  auto per_l1 = [&](auto l1tag) {
-    constexpr int L1 = decltype(l1tag)::value;
-    constexpr int D1 = 2 * L1 + 1;
-    uint4 xh[KS][D1], xl[KS][D1];
-    {
-      float x[KS][8][D1];
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) xload(l1tag, ks, x[ks]);
-      if constexpr (L1 > 0 && G::ok(L1, L1, 0)) {
-        // feature first (into the scalar outputs): f[k] = sum_a z[a] x[k][a], one product group per tile
-        constexpr int T = G::T(0), B0 = G::blk(L1, L1, 0), U0 = G::uoff(L1, L1, 0);
-        float z[D1][1];
-        make_z<L1, L1, 0>(y, z);
-        uint4 fh[KS], fl[KS];
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          float f[8];
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            float s = z[0][0] * x[ks][i][0];
-#pragma unroll
-            for (int a = 1; a < D1; ++a) s = __builtin_fmaf(z[a][0], x[ks][i][a], s);
-            f[i] = s;
-          }
-          split8(f, fh[ks], fl[ks]);
-        }
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int ks = 0; ks < KS; ++ks) {
-            uint4 ah, al;
-            load_w(cx, B0 + ks * T + t, ah, al);
-            acc0[t] = mma3(ah, al, fh[ks], fl[ks], acc0[t]);
-          }
-          if constexpr (FIRST) {  // dst half: fold of the per-node pre-mix
-#pragma unroll
-            for (int a = 0; a < D1; ++a) {
-              const f32x4 u = *reinterpret_cast<const f32x4*>(cx.ud + U0 + (a * T + t) * 16);
-              acc0[t] += u * z[a][0];
-            }
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-        for (int a = 0; a < D1; ++a) {
-          float f[8];
-#pragma unroll
-          for (int i = 0; i < 8; ++i) f[i] = x[ks][i][a];
-          split8(f, xh[ks][a], xl[ks][a]);
-        }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    auto per_path = [&](auto l2tag, auto l3tag) {
-      constexpr int L2 = decltype(l2tag)::value, L3 = decltype(l3tag)::value;
-      if constexpr (G::ok(L1, L2, L3) && !(L3 == 0 && L1 > 0)) {
-        constexpr int D3 = 2 * L3 + 1, T = G::T(L3);
-        constexpr int B0 = G::blk(L1, L2, L3), U0 = G::uoff(L1, L2, L3);
-        float z[D1][D3];
-        make_z<L1, L2, L3>(y, z);
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-          __builtin_amdgcn_sched_barrier(0);
-          f32x4 u[D1];
-#pragma unroll
-          for (int a = 0; a < D1; ++a) {
-            if constexpr (FIRST)
-              u[a] = *reinterpret_cast<const f32x4*>(cx.ud + U0 + (a * T + t) * 16);
-            else
-              u[a] = f32x4{0.f, 0.f, 0.f, 0.f};
-          }
-          if constexpr (FIRST && L1 == 0) {
-            const f32x4 wdv = *reinterpret_cast<const f32x4*>(cx.wd + G::wdoff(L3) + t * 16);
-            u[0] += wdv * cx.dsc;
-          }
-#pragma unroll
-          for (int ks = 0; ks < KS; ++ks) {
-            uint4 ah, al;
-            load_w(cx, B0 + ks * T + t, ah, al);
-#pragma unroll
-            for (int a = 0; a < D1; ++a) u[a] = mma3(ah, al, xh[ks][a], xl[ks][a], u[a]);
-          }
-#pragma unroll
-          for (int c = 0; c < D3; ++c)
-#pragma unroll
-            for (int a = 0; a < D1; ++a)
-              if (z_nonzero<L1, L2, L3>(a, c)) {
-                if constexpr (L3 == 0) acc0[t] += u[a] * z[a][c];
-                else if constexpr (L3 == 1) acc1[t][c] += u[a] * z[a][c];
-                else acc2[t][c] += u[a] * z[a][c];
-              }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    };
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, 1>;
-    using I2 = std::integral_constant<int, 2>;
-    per_path(I0{}, I0{}); per_path(I1{}, I0{}); per_path(I2{}, I0{});
-    per_path(I0{}, I1{}); per_path(I1{}, I1{}); per_path(I2{}, I1{});
-    per_path(I0{}, I2{}); per_path(I1{}, I2{}); per_path(I2{}, I2{});
-  };
-  per_l1(std::integral_constant<int, 0>{});
-  per_l1(std::integral_constant<int, 1>{});
-  if constexpr (LMAX == 2) per_l1(std::integral_constant<int, 2>{});
+  constexpr int KS = MsgGeom<LMAX, TT>::KS;
+  TpState<KS> st;
+  uint4 wh[KS], wl[KS];
+  f32x4 uin[5];
+  tp_prefetch<LMAX, TT, FIRST, 0>(cx, wh, wl, uin);
+  tp_block<LMAX, TT, FIRST, 0>(cx, y, xload, st, acc0, acc1, acc2, wh, wl, uin);
 }
 
 // real "component" spherical harmonics of the edge vector (same expressions as edge_geometry_l2_kernel, e3_edge_ops.hip)
@@ -524,33 +583,23 @@ __global__ __launch_bounds__(256, msg_waves_per_simd(LMAX, TT)) void msg_fused_k
   int64_t wg_hi = wg_lo + tiles_per_wg;
   if (wg_hi > ntiles) wg_hi = ntiles;
 
-  // running segment sum across consecutive tiles of this wave: node id (wave uniform) + one column per lane and group
-  constexpr int NG1 = (3 * H + 63) / 64, NG2 = (5 * H + 63) / 64;
+  // running segment sum across consecutive tiles of this wave: node id (wave uniform) + NQ output columns per lane
+  // (the gated message row [H | 3 H | 5 H] is exactly an `out` row: column 64 q + lane)
+  constexpr int NQ = (D + 63) / 64;
+  constexpr int RS = D + 1;  // LDS row stride of the transposed tile (floats, odd)
   int cur = -1;
-  float carry0 = 0.f, carry1[NG1], carry2[LMAX == 2 ? NG2 : 1];
+  float carry[NQ];
 #pragma unroll
-  for (int q = 0; q < NG1; ++q) carry1[q] = 0.f;
-#pragma unroll
-  for (int q = 0; q < (LMAX == 2 ? NG2 : 1); ++q) carry2[q] = 0.f;
+  for (int q = 0; q < NQ; ++q) carry[q] = 0.f;
   auto flush = [&]() {
     if (cur >= 0) {
-      float* o = out + (int64_t)cur * ldo;
-      if (lane < H) __builtin_amdgcn_global_atomic_fadd_f32(o + lane, carry0);
+      float* o = out + (int64_t)cur * ldo + lane;
 #pragma unroll
-      for (int q = 0; q < NG1; ++q)
-        if (64 * q + lane < 3 * H) __builtin_amdgcn_global_atomic_fadd_f32(o + H + 64 * q + lane, carry1[q]);
-      if constexpr (LMAX == 2) {
-#pragma unroll
-        for (int q = 0; q < NG2; ++q)
-          if (64 * q + lane < 5 * H) __builtin_amdgcn_global_atomic_fadd_f32(o + 4 * H + 64 * q + lane, carry2[q]);
-      }
+      for (int q = 0; q < NQ; ++q)
+        if (64 * q + lane < D) __builtin_amdgcn_global_atomic_fadd_f32(o + 64 * q, carry[q]);
     }
-    carry0 = 0.f;
 #pragma unroll
-    for (int q = 0; q < NG1; ++q) carry1[q] = 0.f;
-#pragma unroll
-    for (int q = 0; q < (LMAX == 2 ? NG2 : 1); ++q) carry2[q] = 0.f;
-    cur = -1;
+    for (int q = 0; q < NQ; ++q) carry[q] = 0.f;
   };
 
   for (int64_t b0 = wg_lo + (int64_t)wave * blk; b0 < wg_hi; b0 += 4 * (int64_t)blk) {
@@ -561,8 +610,9 @@ __global__ __launch_bounds__(256, msg_waves_per_simd(LMAX, TT)) void msg_fused_k
       // per-tile opaque copies of loop-invariant addresses: without them LICM hoists ~50 table reads (200 registers) and
       // the block addresses out of the tile loop and spills them
       uint32_t woff = lane * 16;
-      const float *n1p = n1tab, *n2p = n2tab, *wdp = wdtab;
-      asm volatile("" : "+v"(woff), "+v"(n1p), "+v"(n2p), "+v"(wdp));
+      int tab0 = 0;
+      asm volatile("" : "+v"(woff), "+v"(tab0));
+      const float *n1p = n1tab + tab0, *n2p = n2tab + tab0, *wdp = wdtab + tab0;
       const int64_t e = row0 + (j < nrows ? j : nrows - 1);
       const int sid = src[e], did = dst[e];
       const int sd = j < nrows ? did : -1;
@@ -671,39 +721,39 @@ __global__ __launch_bounds__(256, msg_waves_per_simd(LMAX, TT)) void msg_fused_k
       float amax = 0.f;
       {
         const f32x4* nt = reinterpret_cast<const f32x4*>(n1p) + g;  // slot s at nt[4 s]
-#pragma unroll
-        for (int t = 0; t < TT; ++t) {
-          f32x4 s = a0[t] * nt[4 * t];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) { s[r] = s[r] * sigmoid_(s[r]); amax = fmaxf(amax, fabsf(s[r])); }
-          a0[t] = s;
-        }
-#pragma unroll
-        for (int t = 0; t < TT; ++t) {
-          f32x4 gt = a0[TT + t] * nt[4 * (TT + t)];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) gt[r] = sigmoid_(gt[r]);
-#pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            const f32x4 v = a1[t][c] * nt[4 * (G::slot0(1) + 3 * t + c)] * gt;
-            a1[t][c] = v;
-            amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
-          }
-        }
-        if constexpr (LMAX == 2) {
+        auto gate_block = [&](auto dtag, auto& acc, const int slot, const int gslot) {
+          constexpr int Dc = decltype(dtag)::value;
 #pragma unroll
           for (int t = 0; t < TT; ++t) {
-            f32x4 gt = a0[2 * TT + t] * nt[4 * (2 * TT + t)];
+            const f32x4 gn = nt[4 * (gslot + t)];
+            float gt[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) gt[r] = sigmoid_(gt[r]);
+            for (int r = 0; r < 4; ++r) gt[r] = sigmoid_(a0[gslot + t][r] * gn[r]);
 #pragma unroll
-            for (int c = 0; c < 5; ++c) {
-              const f32x4 v = a2[t][c] * nt[4 * (G::slot0(2) + 5 * t + c)] * gt;
-              a2[t][c] = v;
-              amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+            for (int c = 0; c < Dc; ++c) {
+              const f32x4 nv = nt[4 * (slot + Dc * t + c)];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float v = acc[t][c][r] * nv[r] * gt[r];
+                acc[t][c][r] = v;
+                amax = fmaxf(amax, fabsf(v));
+              }
             }
           }
+        };
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+          const f32x4 nv = nt[4 * t];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float sv = a0[t][r] * nv[r];
+            const float v = sv * sigmoid_(sv);
+            a0[t][r] = v;
+            amax = fmaxf(amax, fabsf(v));
+          }
         }
+        gate_block(std::integral_constant<int, 3>{}, a1, G::slot0(1), TT);
+        if constexpr (LMAX == 2) gate_block(std::integral_constant<int, 5>{}, a2, G::slot0(2), 2 * TT);
       }
       amax = fmaxf(amax, __shfl_xor(amax, 16));
       amax = fmaxf(amax, __shfl_xor(amax, 32));
@@ -714,17 +764,18 @@ __global__ __launch_bounds__(256, msg_waves_per_simd(LMAX, TT)) void msg_fused_k
       wave_sync_lds();
       {
         f32x4* pk = reinterpret_cast<f32x4*>(wbuf) + lane;
+        auto sc4 = [&](const f32x4 v) { return f32x4{v[0] * srow, v[1] * srow, v[2] * srow, v[3] * srow}; };
 #pragma unroll
-        for (int t = 0; t < TT; ++t) pk[64 * t] = a0[t] * srow;
+        for (int t = 0; t < TT; ++t) pk[64 * t] = sc4(a0[t]);
 #pragma unroll
         for (int t = 0; t < TT; ++t)
 #pragma unroll
-          for (int c = 0; c < 3; ++c) pk[64 * (TT + 3 * t + c)] = a1[t][c] * srow;
+          for (int c = 0; c < 3; ++c) pk[64 * (TT + 3 * t + c)] = sc4(a1[t][c]);
         if constexpr (LMAX == 2) {
 #pragma unroll
           for (int t = 0; t < TT; ++t)
 #pragma unroll
-            for (int c = 0; c < 5; ++c) pk[64 * (4 * TT + 5 * t + c)] = a2[t][c] * srow;
+            for (int c = 0; c < 5; ++c) pk[64 * (4 * TT + 5 * t + c)] = sc4(a2[t][c]);
         }
       }
       wave_sync_lds();
@@ -762,78 +813,66 @@ __global__ __launch_bounds__(256, msg_waves_per_simd(LMAX, TT)) void msg_fused_k
         tp_core<LMAX, TT, false>(cx, y, xload, a0, a1, a2);
       }
 
-      // ---- gate #2 and segment sum: per degree block, transpose through LDS ([row][comp][channel]), then lane = output
-      //      column walks the 16 rows and adds runs of equal dst; the last run is carried into the next tile ----
-      const f32x4* nt2 = reinterpret_cast<const f32x4*>(n2p) + g;
-      int cur_end = cur;
-      auto block = [&](auto dtag, auto val, float* carry, const int colbase) {
-        constexpr int Dc = decltype(dtag)::value;  // components of this degree
-        constexpr int RS = Dc * H + 1;             // LDS row stride (floats), odd: [row][column in output order]
-        constexpr int NG = (Dc * H + 63) / 64;
-        wave_sync_lds();
-        float* wp = wbuf + j * RS + 4 * g * Dc;
-#pragma unroll
-        for (int t = 0; t < TT; ++t)
-#pragma unroll
-          for (int c = 0; c < Dc; ++c) {
-            const f32x4 v = val(t, c);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) wp[(16 * t + r) * Dc + c] = v[r];
-          }
-        wave_sync_lds();
-#pragma unroll
-        for (int q = 0; q < NG; ++q) {
-          const int col = 64 * q + lane;
-          const bool cok = col < Dc * H;
-          const float* sp = wbuf + (cok ? col : 0);
-          float acc = carry[q];
-          int run = cur;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int dn = __builtin_amdgcn_readlane(sd, r);
-            if (dn != run && dn >= 0) {
-              if (run >= 0 && cok) __builtin_amdgcn_global_atomic_fadd_f32(out + (int64_t)run * ldo + colbase + col, acc);
-              acc = 0.f;
-              run = dn;
-            }
-            if (dn >= 0) acc += sp[r * RS];
-          }
-          carry[q] = acc;
-          cur_end = run;
-        }
-      };
-      using I1 = std::integral_constant<int, 1>;
-      using I3 = std::integral_constant<int, 3>;
-      using I5 = std::integral_constant<int, 5>;
-      block(I1{}, [&](int t, int) {
-        f32x4 s = a0[t] * nt2[4 * t] * isrow;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) s[r] = s[r] * sigmoid_(s[r]);
-        return s;
-      }, &carry0, 0);
+      // ---- gate #2, then the segment sum: the whole gated tile goes to LDS as [row][output column] (the accumulators are
+      //      dead from here on), lane = output column walks the 16 rows and adds runs of equal dst; the last run is carried
+      //      into the wave's next tile ----
       {
-        f32x4 gt[TT];
+        const f32x4* nt2 = reinterpret_cast<const f32x4*>(n2p) + g;
+        wave_sync_lds();
+        float* wp = wbuf + j * RS + 4 * g;
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
-          gt[t] = a0[TT + t] * nt2[4 * (TT + t)] * isrow;
+          const f32x4 nv = nt2[4 * t];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) gt[t][r] = sigmoid_(gt[t][r]);
+          for (int r = 0; r < 4; ++r) {
+            const float sv = a0[t][r] * nv[r] * isrow;
+            wp[16 * t + r] = sv * sigmoid_(sv);
+          }
         }
-        block(I3{}, [&](int t, int c) { return a1[t][c] * nt2[4 * (G::slot0(1) + 3 * t + c)] * isrow * gt[t]; }, carry1, H);
-      }
-      if constexpr (LMAX == 2) {
-        f32x4 gt[TT];
+        auto put_block = [&](auto dtag, auto& acc, const int slot, const int gslot, float* wq) {
+          constexpr int Dc = decltype(dtag)::value;
 #pragma unroll
-        for (int t = 0; t < TT; ++t) {
-          gt[t] = a0[2 * TT + t] * nt2[4 * (2 * TT + t)] * isrow;
+          for (int t = 0; t < TT; ++t) {
+            const f32x4 gn = nt2[4 * (gslot + t)];
+            float gt[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) gt[t][r] = sigmoid_(gt[t][r]);
+            for (int r = 0; r < 4; ++r) gt[r] = sigmoid_(a0[gslot + t][r] * gn[r] * isrow) * isrow;
+#pragma unroll
+            for (int c = 0; c < Dc; ++c) {
+              const f32x4 nv = nt2[4 * (slot + Dc * t + c)];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) wq[(16 * t + r) * Dc + c] = acc[t][c][r] * nv[r] * gt[r];
+            }
+          }
+        };
+        put_block(std::integral_constant<int, 3>{}, a1, G::slot0(1), TT, wbuf + j * RS + H + 12 * g);
+        if constexpr (LMAX == 2) put_block(std::integral_constant<int, 5>{}, a2, G::slot0(2), 2 * TT, wbuf + j * RS + 4 * H + 20 * g);
+        wave_sync_lds();
+        const float* sp = wbuf + lane;
+#pragma unroll
+        for (int rb = 0; rb < 16; rb += 4) {
+          float v[4][NQ];
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) v[rr][q] = (64 * q + lane < D) ? sp[(rb + rr) * RS + 64 * q] : 0.f;
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const int dn = __builtin_amdgcn_readlane(sd, rb + rr);
+            if (dn >= 0) {
+              if (dn != cur) {
+                flush();
+                cur = dn;
+              }
+#pragma unroll
+              for (int q = 0; q < NQ; ++q) carry[q] += v[rr][q];
+            }
+          }
         }
-        block(I5{}, [&](int t, int c) { return a2[t][c] * nt2[4 * (G::slot0(2) + 5 * t + c)] * isrow * gt[t]; }, carry2, 4 * H);
       }
-      cur = cur_end;
     }
     flush();  // the wave's next tile is not the successor of this one
+    cur = -1;
   }
 }
 
@@ -995,7 +1034,7 @@ int e3_msg_pack_weights(e3_msg_plan* P, const float* const w1[3], const float* c
 
 int e3_msg_forward(e3_msg_plan* P, const float* h, int64_t ld_h, int64_t N, const float* pos4, const int32_t* src,
                    const int32_t* dst, int64_t E, const void* packed, const float* in_scale, float* premix,
-                   float* out, int64_t ld_out, int tiles_per_block, void* stream) {
+                   float* out, int64_t ld_out, int accumulate, int tiles_per_block, void* stream) {
   if (!P || N < 0 || E < 0) return E3_ERR_INVALID_ARG;
   const MsgKernels& k = *P->k;
   if (N == 0) return E3_OK;
@@ -1005,10 +1044,11 @@ int e3_msg_forward(e3_msg_plan* P, const float* h, int64_t ld_h, int64_t N, cons
   int st = msg_ensure_device(P);
   if (st != E3_OK) return st;
   hipStream_t s = (hipStream_t)stream;
-  // out is an accumulation target of atomics: the rows of this launch start from zero
-  E3_HIP_CHECK(hipMemset2DAsync(out, (size_t)ld_out * 4, 0, (size_t)k.D * 4, (size_t)N, s));
+  // out is an accumulation target of atomics: the rows start from zero unless this launch continues an earlier one
+  // (accumulate != 0: same h rows of every dst node, so the pre-mix table of that launch is reused as well)
+  if (!accumulate) E3_HIP_CHECK(hipMemset2DAsync(out, (size_t)ld_out * 4, 0, (size_t)k.D * 4, (size_t)N, s));
   if (E == 0) return E3_OK;
-  {
+  if (!accumulate) {
     const int64_t ntiles = (N + 15) / 16;
     const int grid = (int)std::min<int64_t>((ntiles + 3) / 4, 2048);
     void* args[] = {&h, &ld_h, &N, &packed, &in_scale, &premix};

@@ -1,0 +1,144 @@
+"""Host side of the fused SEGNN message function (``e3_msg_*`` in include/e3gnn.h; kernel: csrc/e3_msg_fused.hip).
+
+    a_i = sum_{e -> i} gate(TP_m2(gate(TP_m1([h_dst | h_src | d_e]; Y_e)); Y_e))
+
+One launch per layer (plus a per-node pre-mix launch): spherical harmonics, both message products, both gates and the
+segment-sum over ``dst``; nothing of size ``E x width`` reaches HBM.  Builder-defined; the two
+tensor products are the ``e3_tp_*`` operators, i.e. the reference operator for l <= 1.  fp32 storage, ROCm tensors only.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _lib, profiling
+from .radius_graph import RadiusGraph
+
+_NAT = ("l0e", "l1o", "l2e")  # natural-parity classes = output degrees 0, 1, 2
+
+
+class FusedMessage:
+    """Plan + packed weights of the fused message kernel for one (l_max, hidden) pair.  Deep-copy / pickle safe."""
+
+    def __init__(self, lmax: int, hidden: int):
+        self.lmax, self.hidden = int(lmax), int(hidden)
+        self._plans = _lib.DevicePlans("e3_msg_plan_create", "e3_msg_plan_destroy", self.lmax, self.hidden)
+        self._packed = {}
+        self.tiles_per_block = 0  # 0 = library default
+
+    def __deepcopy__(self, memo):
+        return FusedMessage(self.lmax, self.hidden)
+
+    def __reduce__(self):
+        return (FusedMessage, (self.lmax, self.hidden))
+
+    @staticmethod
+    def supported(lmax: int, hidden: int) -> bool:
+        return lmax in (1, 2) and hidden in (16, 32, 64)
+
+    @property
+    def width(self) -> int:
+        return self.hidden * (self.lmax + 1) ** 2
+
+    def _tensors(self, tp):
+        ws = [getattr(tp, "weights_" + c, None) for c in _NAT]
+        ns = [getattr(tp, "norm_" + c, None) for c in _NAT]
+        return ws, ns
+
+    def packed(self, msg1, msg2, device) -> torch.Tensor:
+        lib = _lib.load()
+        w1, n1 = self._tensors(msg1)
+        w2, n2 = self._tensors(msg2)
+        ts = w1 + n1 + w2 + n2
+        key = tuple((t.data_ptr(), t._version) if t is not None else None for t in ts)
+        hit = self._packed.get(device)
+        stream = torch.cuda.current_stream(device)
+        if hit is not None and hit[0] == key:
+            if hit[2] != stream.cuda_stream:
+                stream.wait_event(hit[3])
+            return hit[1]
+        h = self._plans.handle(device)
+        for tpi, ws in ((1, w1), (2, w2)):
+            for l in range(self.lmax + 1):
+                rows, cols = ctypes.c_int(), ctypes.c_int()
+                lib.e3_msg_weight_shape(h, tpi, l, ctypes.byref(rows), ctypes.byref(cols))
+                w = ws[l]
+                if w is None or tuple(w.shape) != (rows.value, cols.value) or w.dtype != torch.float32 or w.device != device:
+                    raise RuntimeError(f"fused message: TP #{tpi} weights of degree {l} must be float32 "
+                                       f"[{rows.value}, {cols.value}] on {device}, got "
+                                       f"{None if w is None else (tuple(w.shape), w.dtype, w.device)}")
+        P3 = ctypes.c_void_p * 3
+        keep = [t.detach().contiguous() if t is not None else None for t in ts]
+        ptr = lambda t: t.data_ptr() if (t is not None and t.numel()) else None
+        packed = torch.empty(int(lib.e3_msg_packed_bytes(h)), dtype=torch.uint8, device=device)
+        with torch.cuda.device(device):
+            _lib.check(lib.e3_msg_pack_weights(h, P3(*map(ptr, keep[0:3])), P3(*map(ptr, keep[3:6])),
+                                               P3(*map(ptr, keep[6:9])), P3(*map(ptr, keep[9:12])), packed.data_ptr(),
+                                               stream.cuda_stream), "e3_msg_pack_weights")
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        self._packed[device] = (key, packed, stream.cuda_stream, ev)
+        return packed
+
+    def flops_per_edge(self) -> int:
+        """Algorithmic flops of the two message products per edge: sum over paths of 2 K M min(2 l1+1, 2 l3+1)."""
+        H, L = self.hidden, self.lmax
+        fl = 0
+        for tp, n in ((1, [2 * H + 1, 2 * H, 2 * H]), (2, [H, H, H])):
+            for l3 in range(L + 1):
+                M = H * (1 + L) if l3 == 0 else H
+                for l1 in range(L + 1):
+                    for l2 in range(L + 1):
+                        if abs(l1 - l2) <= l3 <= l1 + l2 and (l1 + l2 + l3) % 2 == 0:
+                            fl += 2 * n[l1] * M * min(2 * l1 + 1, 2 * l3 + 1)
+        return fl
+
+    def forward(self, h: torch.Tensor, g: RadiusGraph, msg1, msg2, in_scale: torch.Tensor | None = None, edges=None,
+                cont=None):
+        """h [N, width] fp32 (Morton order of ``g``) -> aggregated messages [N, width] fp32.
+
+        ``edges = (src, dst)``: an explicit dst-sorted edge list instead of ``g``'s (sharding: interior / boundary edges).
+        ``cont``: the ``(out, premix)`` pair a previous call returned through ``return_state`` semantics -- the call then ADDS
+        its edges' messages to ``out`` (same ``h`` rows for every dst node required) and returns ``out``."""
+        if not h.is_cuda or h.dtype != torch.float32:
+            raise RuntimeError("fused message: float32 ROCm tensor required (no CPU path)")
+        N, W = h.shape
+        if W != self.width or N != g.rowptr.numel() - 1:
+            raise RuntimeError(f"fused message: h must be [{g.rowptr.numel() - 1}, {self.width}], got {tuple(h.shape)}")
+        if h.stride(-1) != 1 or h.stride(0) % 4 or h.data_ptr() % 16:
+            h = h.contiguous()
+        dev = h.device
+        lib = _lib.load()
+        src, dst = (g.src, g.dst) if edges is None else edges
+        E = int(src.numel())
+        assert src.dtype == torch.int32 and dst.dtype == torch.int32 and dst.numel() == E
+        if cont is None:
+            out = torch.empty((N, W), dtype=torch.float32, device=dev)
+        else:
+            out = cont[0]
+        self.last_state = None
+        if N == 0:
+            return out
+        with torch.cuda.device(dev):
+            packed = self.packed(msg1, msg2, dev)
+            if in_scale is None:
+                from . import ops
+                in_scale = ops.pow2_scale([h])
+            hd = self._plans.handle(dev)
+            premix = cont[1] if cont is not None else torch.empty(N * int(lib.e3_msg_premix_floats_per_node(hd)),
+                                                                  dtype=torch.float32, device=dev)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            t0 = profiling.begin() if profiling.enabled() else None
+            _lib.check(lib.e3_msg_forward(hd, h.data_ptr(), h.stride(0), N, g.pos4.data_ptr(), src.data_ptr(),
+                                          dst.data_ptr(), E, packed.data_ptr(), in_scale.data_ptr(), premix.data_ptr(),
+                                          out.data_ptr(), out.stride(0), 0 if cont is None else 1,
+                                          int(self.tiles_per_block), stream), "e3_msg_forward")
+            if t0 is not None:
+                # algorithmic bytes: h read once, positions, the two index columns, aggregated rows written once
+                nb = 4 * N * W + 16 * N + 8 * E + 4 * N * W
+                profiling.end(f"msg_fused lmax={self.lmax} H={self.hidden} E={E}", E, nb, t0,
+                              flops=self.flops_per_edge() * E,
+                              kernel="e3::msg_fused_kernel (+ e3::msg_premix_kernel)<fp16x3 split MFMA>")
+        self.last_state = (out, premix)
+        return out

@@ -76,7 +76,16 @@ def radius_graph(pos: torch.Tensor, r: float, lo=None, hi=None) -> RadiusGraph:
         rowptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
         _lib.check(lib.e3_rg_sort_count(pos.data_ptr(), N, ctypes.byref(p), perm.data_ptr(), pos4.data_ptr(),
                                         rowptr.data_ptr(), ws.data_ptr(), wbytes, stream), "e3_rg_sort_count")
-        E = int(rowptr[-1].item())
+        # the count / scan run in int32 (indices are int32 end to end): a graph with >= 2^31 edges wraps the running sum,
+        # which shows as a negative or decreasing rowptr -- checked here with the same host read that fetches E
+        if N > 0:
+            E, mindeg = torch.stack([rowptr[-1], (rowptr[1:] - rowptr[:-1]).min()]).tolist()
+        else:
+            E, mindeg = int(rowptr[-1].item()), 0
+        if E < 0 or mindeg < 0:
+            raise RuntimeError("radius_graph: the edge count does not fit int32 (>= 2^31 edges); shard the cloud "
+                               "(sharding.SlabHalo) or reduce the cutoff")
+        E = int(E)
         src = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
         _lib.check(lib.e3_rg_fill(N, ctypes.byref(p), pos4.data_ptr(), rowptr.data_ptr(), src.data_ptr(),
                                   ws.data_ptr(), wbytes, stream), "e3_rg_fill")

@@ -25,6 +25,7 @@ from torch import nn
 from . import ops
 from .irreps import Irreps
 from .l1_tensor_prod import L1TensorProduct
+from .message import FusedMessage
 from .radius_graph import RadiusGraph
 from .tensor_product import SHTensorProduct
 
@@ -50,6 +51,8 @@ class SEGNNLayer(nn.Module):
         self.fused = True           # fused gather + TP + gate (+ segment-sum) kernels when the shapes allow it
         self.fuse_scatter = True    # segment-sum by fp32 atomics in the message kernel (sums agree to fp32 rounding, not
         #                             bit for bit); False = separate, bitwise reproducible e3_segment_sum
+        self.fuse_message = True    # fp32: the whole message function in one launch (message.FusedMessage)
+        self._msg = FusedMessage(lmax, H) if FusedMessage.supported(lmax, H) else None
         self.msg1 = _make_tp(hid + hid + Irreps("1x0e"), gated, lmax)
         self.msg2 = _make_tp(hid, gated, lmax)
         self.upd1 = _make_tp(hid + hid, gated, lmax)
@@ -66,37 +69,59 @@ class SEGNNLayer(nn.Module):
             f = self._fused_ok = all(tp.fused_supported(True) for tp in (self.msg1, self.msg2, self.upd1))
         return f
 
-    def forward(self, h, g: RadiusGraph, Y, d, A, h_scale=None):
-        """-> (h_next, operand scale of h_next | None)"""
-        use_fused = self.fused and self.fused_available() and not (torch.is_grad_enabled() and _needs_grad(self, h))
-        if h.dtype == torch.bfloat16 and not use_fused:
+    def forward(self, h, g: RadiusGraph, Y, d, A, h_scale=None, halo=None, split=None):
+        """-> (h_next, operand scale of h_next | None).  ``halo`` / ``split`` (sharding.SlabHalo / SplitGraph): the layer
+        refreshes the ghost rows of ``h`` itself -- in place -- and overlaps the transfer with the interior edges."""
+        inference = not (torch.is_grad_enabled() and _needs_grad(self, h))
+        f32 = h.dtype == torch.float32
+        r16 = self.fused and inference and self.fused_available()   # per-TP fused kernels (gather + TP + gate)
+        if h.dtype == torch.bfloat16 and not r16:
             raise RuntimeError("bf16 storage needs the fused MFMA path (inference, shapes with an MFMA instantiation)")
-        if use_fused:
+        # ---- message function -> aggregated messages a [N, width] ----
+        one_launch = self.fused and inference and f32 and self.fuse_message and self.fuse_scatter and self._msg is not None
+        if halo is not None and not (one_launch and split is not None):
+            halo.exchange(h)  # blocking refresh of the ghost rows, in place
+        if one_launch and halo is not None and split is not None:
+            # the refresh is posted first; interior edges (owned src) run while it is in flight, boundary edges after it
+            # landed.  The operand scale comes from the owned + stale ghost rows: one binade of head room covers the
+            # refreshed ghosts (they are rows of the neighbours' h of the same layer; checked in the sharding tests).
+            tok = halo.start(h)
+            if h_scale is None:
+                h_scale = ops.pow2_scale([h], target_log2=9)
+            a = self._msg.forward(h, split.graph, self.msg1, self.msg2, h_scale, edges=split.interior)
+            halo.finish(h, tok)
+            a = self._msg.forward(h, split.graph, self.msg1, self.msg2, h_scale, edges=split.boundary,
+                                  cont=self._msg.last_state)
+        elif one_launch:
+            # one launch: SH + TP #1 + gate + TP #2 + gate + segment-sum (message.FusedMessage)
+            if h_scale is None:
+                h_scale = ops.pow2_scale([h])
+            a = self._msg.forward(h, g, self.msg1, self.msg2, h_scale)
+        elif r16:
             # gather + concat + TP + gate in one kernel each: no [E, 2D+1] / raw-TP tensors in HBM
             if d.dtype != h.dtype:
                 d = d.to(h.dtype)
-            f32 = h.dtype == torch.float32
-            sc1 = ops.pow2_scale([h, d]) if f32 else None
-            m = self.msg1.forward_fused([(h, g.dst), (h, g.src), (d, None)], Y, gate=True, in_scale=sc1)
-            # message TP #2 with the segment-sum fused into its epilogue where the library has that kernel: the
-            # [E, width] messages are never written; otherwise two kernels
+            m = self.msg1.forward_fused([(h, g.dst), (h, g.src), (d, None)], Y, gate=True,
+                                        in_scale=ops.pow2_scale([h, d]) if f32 else None)
             a = None
-            if self.fuse_scatter:
+            if self.fuse_scatter:  # segment-sum in the epilogue of message TP #2 where the library has that kernel
                 a = self.msg2.forward_fused([(m, None)], Y, gate=True, scatter=(g.dst, g.rowptr.numel() - 1))
             if a is None:
                 m = self.msg2.forward_fused([(m, None)], Y, gate=True)
                 a = ops.segment_sum(m, g)
+        else:
+            m = ops.gather_concat(h, g, d)
+            m = self._gate(self.msg1(m, Y))
+            m = self._gate(self.msg2(m, Y))
+            a = ops.segment_sum(m, g)
+        # ---- node update ----
+        if r16:
             u = self.upd1.forward_fused([(h, None), (a, None)], A, gate=True)
-            u = self.upd2(u, A)
-            if f32:
-                return ops.add_pow2_scale(h, u)
-            return h + u, None
-        m = ops.gather_concat(h, g, d)
-        m = self._gate(self.msg1(m, Y))
-        m = self._gate(self.msg2(m, Y))
-        a = ops.segment_sum(m, g)
-        u = self._gate(self.upd1(torch.cat([h, a], 1), A))
+        else:
+            u = self._gate(self.upd1(torch.cat([h, a], 1), A))
         u = self.upd2(u, A)
+        if f32 and inference:
+            return ops.add_pow2_scale(h, u)
         return h + u, None
 
 
@@ -115,12 +140,15 @@ class SEGNN(nn.Module):
         self.layers = nn.ModuleList([SEGNNLayer(hidden, lmax) for _ in range(num_layers)])
         self.readout = _make_tp(hid, self.out_irreps, lmax)
 
-    def forward(self, x: torch.Tensor, g: RadiusGraph, geometry=None, halo=None) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, g: RadiusGraph, geometry=None, halo=None, split=None) -> torch.Tensor:
         """x [N, in_dim] node features in the graph's (Morton) order -> [N, out_dim] in the same order.
 
         ``halo`` (``sharding.SlabHalo``): when the cloud is spatially sharded, ghost rows of ``h`` are
         refreshed from their owners before every message-passing layer; only owned rows of the result
-        are meaningful."""
+        are meaningful.  ``split`` (``halo.split_graph(g)``): edges into ghost rows dropped and the rest split into
+        interior / boundary lists so that the refresh overlaps the interior edges."""
+        if split is not None:
+            g = split.graph
         Y, d, A = geometry if geometry is not None else ops.edge_geometry(g, lmax=self.lmax)
         if x.dtype == torch.bfloat16 and self.lmax != 2:
             raise RuntimeError("bf16 storage is implemented for l_max = 2 (BASELINE config 3)")
@@ -128,7 +156,6 @@ class SEGNN(nn.Module):
         sc = None
         for layer in self.layers:
             if halo is not None:
-                h = halo.exchange(h)
-                sc = None  # ghost rows changed
-            h, sc = layer(h, g, Y, d, A, sc)
+                sc = None  # the ghost rows are about to change: the scale of the previous layer's output is stale
+            h, sc = layer(h, g, Y, d, A, sc, halo=halo, split=split)
         return self.readout(h, A)

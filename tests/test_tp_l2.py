@@ -222,8 +222,10 @@ def test_gpu_fused_unaligned_output_rows(io):
     g = torch.Generator(device="cuda:0").manual_seed(6)
     m = torch.randn(B, 288, device="cuda:0", generator=g).to(dt)
     Y = torch.randn(B, 9, device="cuda:0", generator=g)
+    from scalable_e3_gnn_amd import ops
+    sc = ops.pow2_scale([m]) if dt == torch.float32 else None
     with torch.no_grad():
-        ref = tp.forward_fused([(m, None)], Y, gate=True)
+        ref = tp.forward_fused([(m, None)], Y, gate=True, in_scale=sc)
     lib = _lib.load()
     plan = tp._plan
     ws, ns = tp._tensors()
@@ -233,8 +235,9 @@ def test_gpu_fused_unaligned_output_rows(io):
     segs = (TPSegment * 1)()
     segs[0].base, segs[0].ld, segs[0].ncols = m.data_ptr(), m.stride(0), 288
     stream = torch.cuda.current_stream().cuda_stream
-    _lib.check(lib.e3_tp_forward_fused(plan.handle, ctypes.byref(segs), 1, Y.data_ptr(), Y.stride(0), packed.data_ptr(),
-                                       buf.data_ptr(), ld, B, _lib.dtype_code(dt), 1, stream), "e3_tp_forward_fused")
+    _lib.check(lib.e3_tp_forward_fused(plan.handle(m.device), ctypes.byref(segs), 1, Y.data_ptr(), Y.stride(0),
+                                       packed.data_ptr(), buf.data_ptr(), ld, B, _lib.dtype_code(dt), 1,
+                                       sc.data_ptr() if sc is not None else None, stream), "e3_tp_forward_fused")
     torch.cuda.synchronize()
     assert torch.equal(buf[:, :288], ref)
     assert bool((buf[:, 288:] == 7.0).all())
