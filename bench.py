@@ -141,6 +141,7 @@ def main():
 
     def make_step(model, x):
         def step():
+            split = None
             if halo is None:
                 g = radius_graph(pos, r, lo, hi)
                 xs = x[g.perm.long()]
@@ -149,8 +150,9 @@ def main():
                 g = radius_graph(lpos, r, lo, hi)
                 halo.renumber(g.perm)
                 xs = lx[g.perm.long()]
+                split = halo.split_graph(g)   # ghost-dst edges dropped; interior edges overlap the per-layer refresh
             with torch.no_grad():
-                out = model(xs, g, halo=halo)
+                out = model(xs, g, halo=halo, split=split)
             return g, out
         return step
 

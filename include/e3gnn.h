@@ -317,6 +317,29 @@ int e3_edge_geometry_l2(const float* pos4, const int32_t* rowptr, const int32_t*
 int e3_gate_blocks(const float* in, int64_t ld_in, float* out, int64_t ld_out, int64_t B, int ns,
                    int nblocks, const int32_t* ls, const int32_t* muls, void* stream);
 
+/* =================================================================================================
+ * Backward of the edge / node stages (fp32): with e3_l1tp_backward / e3_tp_backward they make a whole SEGNN layer
+ * differentiable, i.e. parameter gradients and the force head -dE/dpos (BASELINE.json configs[3]).  The reference's
+ * contract for its own operator is torch autograd (l1_tensor_prod.py:234-299); these are the same for the stages it lacks.
+ *   e3_edge_geometry_backward : g_pos [N,3] (zero-filled by the call) from g_edge_y [E,(lmax+1)^2], g_edge_d [E],
+ *                               g_node_a [N,(lmax+1)^2] (any may be NULL); atomics on g_pos.
+ *   e3_gather_concat_backward : g_out [E, 2D+n_extra] -> g_h [N,D] (zero-filled by the call; dst rows summed per CSR row,
+ *                               src rows by atomics), g_extra [E,n_extra] (may be NULL).
+ *   e3_gate_blocks_backward   : in = the forward's input [B, ns+ngates+wide], g_out [B, ns+wide] -> g_in (same layout
+ *                               as in); e3_gate is the one-block case {l = 1, mul = nv}.
+ *   e3_segment_sum_backward   : g_msg[e] = g_agg[dst(e)].
+ * ================================================================================================= */
+int e3_edge_geometry_backward(const float* pos4, const int32_t* rowptr, const int32_t* src, int64_t N, int lmax,
+                              const float* g_edge_y, const float* g_edge_d, const float* g_node_a, float* g_pos,
+                              void* stream);
+int e3_gather_concat_backward(const float* g_out, int64_t ld_gout, int D, const int32_t* rowptr, const int32_t* src,
+                              int64_t N, int n_extra, float* g_h, int64_t ld_gh, float* g_extra, void* stream);
+int e3_gate_blocks_backward(const float* in, int64_t ld_in, const float* g_out, int64_t ld_gout, float* g_in,
+                            int64_t ld_gin, int64_t B, int ns, int nblocks, const int32_t* ls, const int32_t* muls,
+                            void* stream);
+int e3_segment_sum_backward(const float* g_agg, int64_t ld_gagg, const int32_t* rowptr, int64_t N, int D, float* g_msg,
+                            int64_t ld_gmsg, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -69,6 +69,13 @@ SIGNATURES = {
     "e3_msg_pack_weights": (c_int, [c_void_p, c_void_p * 3, c_void_p * 3, c_void_p * 3, c_void_p * 3, c_void_p, c_void_p]),
     "e3_msg_forward": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
                                c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "e3_edge_geometry_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_void_p]),
+    "e3_gather_concat_backward": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64,
+                                          c_void_p, c_void_p]),
+    "e3_gate_blocks_backward": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int,
+                                        POINTER(c_int32), POINTER(c_int32), c_void_p]),
+    "e3_segment_sum_backward": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p]),
     "e3_pow2_scale": (c_int, [c_void_p, POINTER(c_int64), c_int, c_int, c_void_p, c_void_p]),
     "e3_add_pow2_scale": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "e3_tp_backward": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p,

@@ -287,15 +287,26 @@ struct TpState {
   float z[5][5];               // coupling of the current path
 };
 
-template <int LMAX, int TT, bool FIRST, int IDX>
-__device__ __forceinline__ void tp_prefetch(const TpCtx& cx, uint4 (&wh)[MsgGeom<LMAX, TT>::KS],
-                                            uint4 (&wl)[MsgGeom<LMAX, TT>::KS], f32x4 (&uin)[5]) {
+// weights of block IDX and, for product #1, its pre-mix values, both requested one block ahead.  (Measured on 1 M
+// particles: a weight prefetch distance of two blocks costs 8 registers -> spills -> 27.1 vs 26.0 ms; touching the
+// pre-mix rows of the tile's dst nodes ahead of product #1 (L2 warm-up) 25.9 vs 26.2 ms: neither is kept.)
+template <int LMAX, int TT, int IDX>
+__device__ __forceinline__ void tp_prefetch_w(const TpCtx& cx, uint4 (&wh)[MsgGeom<LMAX, TT>::KS],
+                                              uint4 (&wl)[MsgGeom<LMAX, TT>::KS]) {
   using G = MsgGeom<LMAX, TT>;
-  constexpr BlkDesc B = BlkList<LMAX, TT>::at(IDX);
-  constexpr int T = G::T(B.l3), B0 = G::blk(B.l1, B.l2, B.l3), U0 = G::uoff(B.l1, B.l2, B.l3);
+  if constexpr (IDX < BlkList<LMAX, TT>::count()) {
+    constexpr BlkDesc B = BlkList<LMAX, TT>::at(IDX);
+    constexpr int T = G::T(B.l3), B0 = G::blk(B.l1, B.l2, B.l3);
 #pragma unroll
-  for (int ks = 0; ks < G::KS; ++ks) load_w(cx, B0 + ks * T + B.t, wh[ks], wl[ks]);
-  if constexpr (FIRST) {
+    for (int ks = 0; ks < G::KS; ++ks) load_w(cx, B0 + ks * T + B.t, wh[ks], wl[ks]);
+  }
+}
+template <int LMAX, int TT, bool FIRST, int IDX>
+__device__ __forceinline__ void tp_prefetch_u(const TpCtx& cx, f32x4 (&uin)[5]) {
+  using G = MsgGeom<LMAX, TT>;
+  if constexpr (FIRST && IDX < BlkList<LMAX, TT>::count()) {
+    constexpr BlkDesc B = BlkList<LMAX, TT>::at(IDX);
+    constexpr int T = G::T(B.l3), U0 = G::uoff(B.l1, B.l2, B.l3);
 #pragma unroll
     for (int a = 0; a < 2 * B.l1 + 1; ++a) uin[a] = *reinterpret_cast<const f32x4*>(cx.ud + U0 + (a * T + B.t) * 16);
   }
@@ -314,9 +325,10 @@ __device__ __forceinline__ void tp_block(const TpCtx& cx, const float (&y)[9], X
   constexpr int L1 = B.l1, L2 = B.l2, L3 = B.l3, t = B.t;
   constexpr int D1 = 2 * L1 + 1, D3 = 2 * L3 + 1;
   // ---- the next block's operands are requested first ----
-  uint4 nwh[KS], nwl[KS];
+  uint4 wh2[KS], wl2[KS];
   f32x4 nu[5];
-  if constexpr (IDX + 1 < BL::count()) tp_prefetch<LMAX, TT, FIRST, IDX + 1>(cx, nwh, nwl, nu);
+  tp_prefetch_w<LMAX, TT, IDX + 1>(cx, wh2, wl2);
+  tp_prefetch_u<LMAX, TT, FIRST, IDX + 1>(cx, nu);
   // ---- first block of a degree: inputs, feature-first operand, (hi, lo) halves ----
   if constexpr (B.first_of_l1) {
     float x[KS][8][D1];
@@ -400,7 +412,7 @@ __device__ __forceinline__ void tp_block(const TpCtx& cx, const float (&y)[9], X
         }
   }
   if constexpr (IDX + 1 < BL::count())
-    tp_block<LMAX, TT, FIRST, IDX + 1>(cx, y, xload, st, acc0, acc1, acc2, nwh, nwl, nu);
+    tp_block<LMAX, TT, FIRST, IDX + 1>(cx, y, xload, st, acc0, acc1, acc2, wh2, wl2, nu);
 }
 
 // One tensor product on the lane's 16-edge tile.  XLOAD(l1tag, ks, x[8][D1]) delivers the (scaled) fp32 inputs of this
@@ -413,7 +425,8 @@ __device__ __forceinline__ void tp_core(const TpCtx& cx, const float (&y)[9], XL
   TpState<KS> st;
   uint4 wh[KS], wl[KS];
   f32x4 uin[5];
-  tp_prefetch<LMAX, TT, FIRST, 0>(cx, wh, wl, uin);
+  tp_prefetch_w<LMAX, TT, 0>(cx, wh, wl);
+  tp_prefetch_u<LMAX, TT, FIRST, 0>(cx, uin);
   tp_block<LMAX, TT, FIRST, 0>(cx, y, xload, st, acc0, acc1, acc2, wh, wl, uin);
 }
 
@@ -602,19 +615,29 @@ __global__ __launch_bounds__(256, msg_waves_per_simd(LMAX, TT)) void msg_fused_k
     for (int q = 0; q < NQ; ++q) carry[q] = 0.f;
   };
 
+  // edge ids are fetched one tile ahead (the tile's first instructions need them for the gather addresses)
+  auto load_ids = [&](int64_t tile, int& s_, int& d_) {
+    const int64_t row0 = tile * 16;
+    const int nrows = (int)((E - row0) < 16 ? (E - row0) : 16);
+    const int64_t e = row0 + (j < nrows ? j : nrows - 1);
+    s_ = src[e];
+    d_ = dst[e];
+  };
   for (int64_t b0 = wg_lo + (int64_t)wave * blk; b0 < wg_hi; b0 += 4 * (int64_t)blk) {
     const int64_t b1 = b0 + blk < wg_hi ? b0 + blk : wg_hi;
+    int sid_n = 0, did_n = 0;
+    load_ids(b0, sid_n, did_n);
     for (int64_t tile = b0; tile < b1; ++tile) {
       const int64_t row0 = tile * 16;
       const int nrows = (int)((E - row0) < 16 ? (E - row0) : 16);
+      const int sid = sid_n, did = did_n;
+      if (tile + 1 < b1) load_ids(tile + 1, sid_n, did_n);
       // per-tile opaque copies of loop-invariant addresses: without them LICM hoists ~50 table reads (200 registers) and
       // the block addresses out of the tile loop and spills them
       uint32_t woff = lane * 16;
       int tab0 = 0;
       asm volatile("" : "+v"(woff), "+v"(tab0));
       const float *n1p = n1tab + tab0, *n2p = n2tab + tab0, *wdp = wdtab + tab0;
-      const int64_t e = row0 + (j < nrows ? j : nrows - 1);
-      const int sid = src[e], did = dst[e];
       const int sd = j < nrows ? did : -1;
 
       // ---- stage the 16 h[src] rows by 16-byte LDS-DMA (the per-lane source address is the gather).  LDS image per wave:
@@ -640,12 +663,13 @@ __global__ __launch_bounds__(256, msg_waves_per_simd(LMAX, TT)) void msg_fused_k
           } else {
             constexpr int RPI = 64 / UNITS;  // rows per instruction
             const int u = lane & (UNITS - 1), rl = lane / UNITS;
+            int rid[16 / RPI];  // all shuffles first: they are LDS-pipe instructions, and hipcc guards every LDS access
+#pragma unroll                  // behind an LDS-DMA in flight with vmcnt(0), which would serialise the copies
+            for (int it = 0; it < 16 / RPI; ++it) rid[it] = __shfl(sid, it * RPI + rl);
 #pragma unroll
-            for (int it = 0; it < 16 / RPI; ++it) {
-              const int rid = __shfl(sid, it * RPI + rl);
-              __builtin_amdgcn_global_load_lds((glb_void_t*)(h + (int64_t)rid * ldh + SRCOFF + u * 4),
+            for (int it = 0; it < 16 / RPI; ++it)
+              __builtin_amdgcn_global_load_lds((glb_void_t*)(h + (int64_t)rid[it] * ldh + SRCOFF + u * 4),
                                                (lds_void_t*)(dstf + it * 256), 16, 0, 0);
-            }
           }
         };
         if constexpr (LMAX == 2) {

@@ -1,7 +1,8 @@
-"""world_size-2 gloo test of the spatial sharding (slab partition + ghost halo, product code in
-scalable-e3-gnn_amd/sharding.py).  The GPU kernels cannot run here, so the per-rank compute uses the
-numpy oracle; what is under test is the partition, the ghost bookkeeping across the Morton renumbering
-and the per-layer exchange: the sharded forward must equal the unsharded oracle forward."""
+"""gloo tests (world_size 2 and 4, CPU) of the spatial sharding: slab partition + ghost halo + split edge lists, product
+code in scalable-e3-gnn_amd/sharding.py.  The GPU kernels cannot run here, so the per-rank compute uses the numpy
+oracle; what is under test is the partition, the ghost bookkeeping across the Morton renumbering (ranks with ONE and
+with TWO neighbours, ranks whose halo is empty), the in-place per-layer refresh and the interior / boundary split: the
+sharded forward on the split graph must equal the unsharded oracle forward."""
 import os
 import socket
 import sys
@@ -23,21 +24,37 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, N, H, L, out_q):
+def _cloud(kind, N, world):
+    g = torch.Generator().manual_seed(7)
+    pos = torch.rand(N, 3, generator=g, dtype=torch.float64)
+    if kind == "uniform":
+        pos[:, 0] *= world                                   # global box [0,world) x [0,1)^2
+    elif kind == "clustered":
+        # non-uniform: 70 % of the particles in a blob that straddles the 1|2 face, rank 3's slab almost empty
+        blob = torch.rand(N, generator=g) < 0.7
+        pos[:, 0] = torch.where(blob, 2.0 + 0.35 * torch.randn(N, generator=g, dtype=torch.float64), pos[:, 0] * world)
+        pos[:, 0].clamp_(0.0, world - 1e-9)
+    elif kind == "gap":
+        # rank 1's slab holds nothing near its faces and rank 2's slab is EMPTY: empty halos and empty messages
+        u = torch.rand(N, generator=g, dtype=torch.float64)
+        pos[:, 0] = torch.where(u < 0.5, 0.9 * u / 0.5, torch.where(u < 0.6, 1.4 + 0.2 * (u - 0.5) / 0.1, 3.0 + (u - 0.6) / 0.4))
+    x = torch.randn(N, 4, generator=g, dtype=torch.float64)
+    return pos, x
+
+
+def _worker(rank, world, port, N, H, L, kind, out_q):
     sys.path.insert(0, REPO)
     import models  # noqa
     from oracle import graph_oracle as G
     from oracle import segnn_oracle as S
+    from scalable_e3_gnn_amd.radius_graph import RadiusGraph
     from scalable_e3_gnn_amd.segnn import SEGNN
     from scalable_e3_gnn_amd.sharding import SlabHalo
 
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        g = torch.Generator().manual_seed(7)
-        pos = torch.rand(N, 3, generator=g, dtype=torch.float64)
-        pos[:, 0] *= world                                   # global box [0,world) x [0,1)^2
-        x = torch.randn(N, 4, generator=g, dtype=torch.float64)
+        pos, x = _cloud(kind, N, world)
         r = float((3 * 10.0 / (4 * np.pi * (N / world))) ** (1 / 3))
         torch.manual_seed(0)
         model = SEGNN("1x0e+1x1o", H, "1x1o", L)             # ctor only (no GPU needed)
@@ -53,15 +70,47 @@ def _worker(rank, world, port, N, H, L, out_q):
         assert p32.dtype == torch.float32 and f16.dtype == torch.bfloat16 and f16.shape[0] == p32.shape[0]
         assert torch.equal(f16[: own.numel()], x[own].to(torch.bfloat16))
         lo, hi = [rank - 2 * r, 0, 0], [rank + 1 + 2 * r, 1, 1]
-        perm, rowptr, src = G.graph(lpos.numpy(), lo, hi, r)
+        nloc = lpos.shape[0]
+        if nloc:
+            perm, rowptr, src = G.graph(lpos.numpy(), lo, hi, r)
+        else:
+            perm, rowptr, src = np.zeros(0, np.int32), np.zeros(1, np.int32), np.zeros(0, np.int32)
         halo.renumber(torch.as_tensor(perm))
         lp, lxx = lpos.numpy().astype(np.float32)[perm], lx.numpy()[perm]
+        # split graph: edges into ghost rows dropped, the rest = interior (owned src) + boundary (ghost src)
+        g = RadiusGraph(torch.as_tensor(perm), torch.zeros(nloc, 4), torch.as_tensor(rowptr), torch.as_tensor(src),
+                        len(src), ((1, 1, 1), 0))
+        sp = halo.split_graph(g)
+        gs, gd = sp.graph.src.numpy(), sp.graph.dst.numpy()
+        ghost = halo.is_ghost.numpy()
+        assert not ghost[gd].any() and sp.dropped == len(src) - len(gs)
+        assert np.array_equal(np.diff(sp.graph.rowptr.numpy()), np.bincount(gd, minlength=nloc))
+        (isrc, idst), (bsrc, bdst) = [(a.numpy(), b.numpy()) for a, b in (sp.interior, sp.boundary)]
+        assert not ghost[isrc].any() and (len(bsrc) == 0 or ghost[bsrc].all())
+        assert len(isrc) + len(bsrc) == len(gs)
+        both = np.concatenate([np.stack([idst, isrc], 1), np.stack([bdst, bsrc], 1)])
+        assert np.array_equal(both[np.lexsort((both[:, 1], both[:, 0]))], np.stack([gd, gs], 1))  # same edge multiset
+        assert np.all(np.diff(idst) >= 0) and np.all(np.diff(bdst) >= 0)                          # both still dst-sorted
+
+        calls = []
 
         def exchange(h):
-            return halo.exchange(torch.as_tensor(h)).numpy()
+            t = torch.as_tensor(h)
+            before = t.data_ptr()
+            tok = halo.start(t)                              # the overlapped form: post, (compute), finish in place
+            out = halo.finish(t, tok)
+            assert out.data_ptr() == before                  # refreshed in place, no clone of h
+            calls.append(1)
+            return out.numpy()
 
-        out = S.forward(params, H, L, "1x0e+1x1o", "1x1o", lxx, lp, rowptr, src, exchange=exchange)
-        owned_out = out[halo.owned_new.numpy()]              # back to the owned particles' original order
+        if nloc:
+            out = S.forward(params, H, L, "1x0e+1x1o", "1x1o", lxx, lp, sp.graph.rowptr.numpy(), gs, exchange=exchange)
+            owned_out = out[halo.owned_new.numpy()]          # back to the owned particles' original order
+        else:
+            for _ in range(L):
+                exchange(np.zeros((0, 4 * H)))               # an empty rank still takes part in every exchange
+            owned_out = np.zeros((0, 3))
+        assert len(calls) == L
         if rank == 0:
             # unsharded reference on the whole cloud
             gperm, grp, gsrc = G.graph(pos.numpy(), [0, 0, 0], [world, 1, 1], r)
@@ -70,22 +119,21 @@ def _worker(rank, world, port, N, H, L, out_q):
             full[gperm] = want                               # original particle order
             out_q.put(("ref", full, None))
         out_q.put(("part", owned_out, own.numpy()))
-        out_q.put(("halo", np.array([halo.n_ghost_left, halo.n_ghost_right, halo.bytes_last_exchange]), rank))
+        out_q.put(("halo", np.array([halo.n_ghost_left, halo.n_ghost_right, halo.bytes_last_exchange, own.numel(),
+                                     sp.dropped, len(isrc), len(bsrc)]), rank))
         dist.barrier()
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.timeout(300)
-def test_sharded_forward_equals_unsharded_world2():
-    world, N, H, L = 2, 1600, 4, 3
+def _run(world, N, H, L, kind):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, N, H, L, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, N, H, L, kind, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = [q.get(timeout=240) for _ in range(1 + 2 * world)]
+    got = [q.get(timeout=280) for _ in range(1 + 2 * world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -96,6 +144,35 @@ def test_sharded_forward_equals_unsharded_world2():
             merged[idx] = val
     assert not np.isnan(merged).any(), "every particle must be owned by exactly one rank"
     assert np.abs(merged - ref).max() / np.abs(ref).max() < 1e-10
-    halos = {idx: val for tag, val, idx in got if tag == "halo"}
+    return {idx: val for tag, val, idx in got if tag == "halo"}
+
+
+@pytest.mark.timeout(300)
+def test_sharded_forward_equals_unsharded_world2():
+    halos = _run(2, 1600, 4, 3, "uniform")
     assert halos[0][0] == 0 and halos[1][1] == 0            # outer faces have no ghosts
     assert halos[0][1] > 0 and halos[1][0] > 0 and halos[0][2] > 0
+    assert all(h[4] > 0 and h[5] > 0 and h[6] > 0 for h in halos.values())  # dropped / interior / boundary edges all occur
+
+
+@pytest.mark.timeout(300)
+def test_sharded_forward_world4_middle_ranks_have_two_neighbours():
+    halos = _run(4, 2400, 4, 2, "uniform")
+    assert halos[0][0] == 0 and halos[3][1] == 0
+    for k in (1, 2):                                         # middle ranks: ghosts from BOTH sides
+        assert halos[k][0] > 0 and halos[k][1] > 0
+
+
+@pytest.mark.timeout(300)
+def test_sharded_forward_world4_clustered_cloud():
+    halos = _run(4, 2400, 4, 2, "clustered")
+    own = [int(halos[k][3]) for k in range(4)]
+    assert max(own) > 3 * max(1, min(own))                   # the partition really is unbalanced
+
+
+@pytest.mark.timeout(300)
+def test_sharded_forward_world4_empty_rank_and_empty_halos():
+    halos = _run(4, 2000, 4, 2, "gap")
+    assert halos[2][3] == 0                                  # rank 2 owns nothing
+    assert halos[1][0] == 0 or halos[1][1] == 0              # rank 1 has an empty halo on at least one side
+    assert halos[3][0] == 0                                  # nothing arrives from the empty slab

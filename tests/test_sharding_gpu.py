@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, N, H, L, q):
+def _worker(rank, world, port, N, H, L, lmax, q):
     sys.path.insert(0, REPO)
     import torch.distributed as dist
     import models  # noqa
@@ -31,15 +31,19 @@ def _worker(rank, world, port, N, H, L, q):
         x = torch.randn(N, 4, generator=g0)
         r = float((3 * 16.0 / (4 * np.pi * (N / world))) ** (1 / 3))
         torch.manual_seed(0)
-        model = SEGNN("1x0e+1x1o", H, "1x1o", L).to(dev)
+        model = SEGNN("1x0e+1x1o", H, "1x1o", L, lmax=lmax).to(dev)
         own = ((pos[:, 0] >= rank) & (pos[:, 0] < rank + 1)).nonzero().flatten()
         halo = SlabHalo()
         lpos, lx = halo.setup(pos[own].to(dev), x[own].to(dev), float(rank), float(rank + 1), r)
         g = radius_graph(lpos, r, [rank - 2 * r, 0, 0], [rank + 1 + 2 * r, 1, 1])
         halo.renumber(g.perm)
+        split = halo.split_graph(g)
         with torch.no_grad():
-            out = model(lx[g.perm.long()], g, halo=halo)
-        q.put(("part", out[halo.owned_new].cpu().numpy(), own.numpy()))
+            out = model(lx[g.perm.long()], g, halo=halo, split=split)   # overlapped refresh, interior / boundary edges
+            out_b = model(lx[g.perm.long()], g, halo=halo)              # blocking refresh on the unsplit graph
+        o, ob = out[halo.owned_new], out_b[halo.owned_new]
+        assert float((o - ob).abs().max() / ob.abs().max()) < 2e-5
+        q.put(("part", o.cpu().numpy(), own.numpy()))
         if rank == 0:
             gg = radius_graph(pos.to(dev), r, [0, 0, 0], [world, 1, 1])
             with torch.no_grad():
@@ -53,12 +57,13 @@ def _worker(rank, world, port, N, H, L, q):
 
 
 @pytest.mark.timeout(300)
-def test_sharded_gpu_forward_equals_single_process():
-    world, N, H, L = 2, 20000, 16, 3
+@pytest.mark.parametrize("H,lmax", [(16, 1), (32, 2)])
+def test_sharded_gpu_forward_equals_single_process(H, lmax):
+    world, N, L = 2, 20000, 3
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, N, H, L, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, N, H, L, lmax, q)) for r in range(world)]
     for p in procs:
         p.start()
     got = [q.get(timeout=240) for _ in range(world + 1)]

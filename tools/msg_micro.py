@@ -5,6 +5,9 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import models  # noqa
+from scalable_e3_gnn_amd import _lib as _L
+if os.environ.get("E3_EXP_LIB"):  # experiment build (tools/build_variant.sh), development only
+    _L.LIB_PATH = os.path.join(os.path.dirname(_L.LIB_PATH), "exp", f"libe3gnn_{os.environ['E3_EXP_LIB']}.so")
 from scalable_e3_gnn_amd import ops
 from scalable_e3_gnn_amd.radius_graph import radius_graph
 from scalable_e3_gnn_amd.segnn import SEGNNLayer
@@ -20,8 +23,10 @@ D = H * (lmax + 1) ** 2
 h = torch.randn(N, D, device=dev)
 sc = ops.pow2_scale([h])
 edges = None
-if os.environ.get("ZERO_IDX"):
+if os.environ.get("ZERO_IDX"):   # every h[src] gather hits row 0
     edges = (torch.zeros_like(g.src), g.dst)
+if os.environ.get("ZERO_DST"):   # every pre-mix row is row 0 and nothing is ever flushed (one run): no U misses, no atomics
+    edges = ((edges[0] if edges else g.src), torch.zeros_like(g.dst))
 E = g.num_edges
 for tpb in [int(v) for v in os.environ.get("TPB", "0").split(",")]:
     layer._msg.tiles_per_block = tpb
@@ -36,5 +41,5 @@ for tpb in [int(v) for v in os.environ.get("TPB", "0").split(",")]:
         e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     fl = layer._msg.flops_per_edge() * E
-    print(f"N={N} E={E} lmax={lmax} H={H} tpb={tpb} zero_idx={bool(edges)}: {ms:.2f} ms/launch pair  {E/ms/1e3:.0f} Medges/s  "
+    print(f"[{os.environ.get('E3_EXP_LIB','default')}] N={N} E={E} lmax={lmax} H={H} tpb={tpb} zero_idx={bool(edges)}: {ms:.2f} ms/launch pair  {E/ms/1e3:.0f} Medges/s  "
           f"{fl/ms/1e9:.1f} TFLOP/s algorithmic ({3*fl/ms/1e9/2500*100:.1f} % of bf16/f16 MFMA peak executed x3)")
