@@ -205,3 +205,72 @@ def forward_l2_torch_cpu(params, H, num_layers, in_irreps, out_irreps, x, pos, r
         u = g(tp2(p + ".upd1", torch.cat([h, a], 1), A, f"{hid}+{hid}", gated))
         h = h + tp2(p + ".upd2", u, A, hid, hid)
     return tp2("readout", h, A, hid, out_irreps)
+
+
+def sh_component_torch(lmax, rel):
+    """torch, differentiable: [E,3] -> [E,(lmax+1)^2] component-normalised real SH (basis of oracle/cg.py)."""
+    import torch
+    d = rel.norm(dim=1, keepdim=True)
+    u = rel / d.clamp_min(1e-300)
+    x, y, z = u[:, 0], u[:, 1], u[:, 2]
+    out = [torch.ones_like(d), (3.0 ** 0.5) * u]
+    if lmax == 2:
+        s3 = 3.0 ** 0.5
+        b = torch.stack([s3 * x * y, s3 * y * z, (2 * z * z - x * x - y * y) / 2, s3 * z * x, s3 / 2 * (x * x - y * y)], 1)
+        out.append((5.0 ** 0.5) * b)
+    return torch.cat(out, 1), d[:, 0]
+
+
+def energy_forces_torch(params, H, num_layers, lmax, in_irreps, x, pos, rowptr, src, mol, n_mol):
+    """fp64 torch-CPU autograd oracle of the energy / force head: per-molecule energies (sum of the 1x0e node readout),
+    forces = -dE/dpos, and dE_total/dparam for every parameter.  Same model definition as ``forward`` / ``forward_l2``
+    (the tensor products go through ``tp_oracle.forward_torch_cpu``, which is dtype-generic torch code)."""
+    import torch
+    from . import tp_oracle as T
+    hid = f"{H}x0e+{H}x1o" + (f"+{H}x2e" if lmax == 2 else "")
+    gated = f"{H}x0e+{lmax * H}x0e+{H}x1o" + (f"+{H}x2e" if lmax == 2 else "")
+    rowptr_t, src_t = torch.as_tensor(rowptr).long(), torch.as_tensor(src).long()
+    N = rowptr_t.numel() - 1
+    deg = rowptr_t[1:] - rowptr_t[:-1]
+    dst_t = torch.repeat_interleave(torch.arange(N), deg)
+    pos = torch.as_tensor(pos, dtype=torch.float64).clone().requires_grad_(True)
+    P = {k: torch.as_tensor(v, dtype=torch.float64).clone().requires_grad_(k.split(".")[-1].startswith("weights_"))
+         for k, v in params.items()}
+    Y, d = sh_component_torch(lmax, pos[src_t] - pos[dst_t])
+    ny = (lmax + 1) ** 2
+    A = torch.zeros(N, ny, dtype=torch.float64)
+    A = torch.cat([torch.ones(N, 1, dtype=torch.float64),
+                   torch.zeros(N, ny - 1, dtype=torch.float64).index_add(0, dst_t, Y[:, 1:]) / deg.clamp_min(1)[:, None]], 1)
+
+    def tp2(prefix, in1, in2, ii, oi):
+        W = {c: P[f"{prefix}.weights_{c}"] for c in T.CLASSES if f"{prefix}.weights_{c}" in P}
+        Nn = {c: P[f"{prefix}.norm_{c}"] for c in T.CLASSES if f"{prefix}.norm_{c}" in P}
+        for c in T.CLASSES:
+            Nn.setdefault(c, torch.ones(0, dtype=torch.float64))
+        return T.forward_torch_cpu(ii, oi, lmax, in1, in2, W, Nn)
+
+    def g(t):
+        out = [torch.nn.functional.silu(t[:, :H])]
+        g0, c0 = H, H + lmax * H
+        for l in range(1, lmax + 1):
+            w = 2 * l + 1
+            out.append((torch.sigmoid(t[:, g0:g0 + H])[:, :, None] * t[:, c0:c0 + H * w].reshape(-1, H, w)).reshape(-1, H * w))
+            g0 += H
+            c0 += H * w
+        return torch.cat(out, 1)
+
+    h = tp2("embed", torch.as_tensor(x, dtype=torch.float64), A, in_irreps, hid)
+    for l in range(num_layers):
+        p = f"layers.{l}"
+        m = torch.cat([h[dst_t], h[src_t], d[:, None]], 1)
+        m = g(tp2(p + ".msg1", m, Y, f"{hid}+{hid}+1x0e", gated))
+        m = g(tp2(p + ".msg2", m, Y, hid, gated))
+        a = torch.zeros_like(h).index_add(0, dst_t, m)
+        u = g(tp2(p + ".upd1", torch.cat([h, a], 1), A, f"{hid}+{hid}", gated))
+        h = h + tp2(p + ".upd2", u, A, hid, hid)
+    e_node = tp2("readout", h, A, hid, "1x0e")[:, 0]
+    energy = torch.zeros(n_mol, dtype=torch.float64).index_add(0, torch.as_tensor(mol).long(), e_node)
+    leaves = [pos] + [v for v in P.values() if v.requires_grad]
+    grads = torch.autograd.grad(energy.sum(), leaves)
+    names = [k for k, v in P.items() if v.requires_grad]
+    return (energy.detach().numpy(), -grads[0].numpy(), {k: g_.numpy() for k, g_ in zip(names, grads[1:])})

@@ -5,9 +5,10 @@ A batch of molecules is ONE radius graph: the molecules are laid out on a 3-D la
 molecule by two cutoff radii, so the cell-list builder (`e3_rg_*`) finds exactly the intra-molecular pairs in one pass,
 with the same kernels as the single-cloud path.  The neighbour search runs on the lattice copy; the graph that is
 returned carries the ORIGINAL coordinates, so edge vectors / spherical harmonics see no shift rounding.  The energy
-head is the per-molecule sum of a scalar (`1x0e`) node readout.  Forces (-dE/dpos) need gradients through the whole
-message pass: the tensor product has its backward (`e3_tp_backward`), the edge-geometry / gather / gate / segment-sum
-kernels do not yet: requesting forces raises.
+head is the per-molecule sum of a scalar (`1x0e`) node readout.  The force head is -dE/dpos by reverse-mode autograd
+through the whole message pass: every stage has a HIP backward (tensor products: `e3_l1tp_backward` / `e3_tp_backward`;
+edge geometry, gather/concat, gates, segment-sum: `e3_*_backward`, csrc/e3_edge_bwd.hip).  First order only: forces can
+be predicted and energies trained on; training ON forces would need the second derivative, which is not implemented.
 """
 from __future__ import annotations
 
@@ -59,10 +60,20 @@ class BatchedEnergyModel(nn.Module):
         self.net = SEGNN(in_irreps, hidden, "1x0e", num_layers, lmax=lmax)
 
     def forward(self, x: torch.Tensor, pos: torch.Tensor, batch: torch.Tensor, r: float, forces: bool = False):
-        if forces:
-            raise NotImplementedError("forces need backward kernels for edge geometry / gather / gate / segment-sum "
-                                      "(the tensor product has one): DESIGN.md §8")
+        """-> energies [n_mol]; with ``forces=True``: (energies, forces [N,3] = -dE/dpos in the caller's atom order)."""
+        from . import ops
         g, mol = batched_radius_graph(pos, batch, r)
-        e_node = self.net(x[g.perm.long()], g)
         n_mol = int(batch.max().item()) + 1 if batch.numel() else 0
-        return torch.zeros(n_mol, dtype=e_node.dtype, device=e_node.device).index_add_(0, mol, e_node[:, 0])
+        perm = g.perm.long()
+        if not forces:
+            e_node = self.net(x[perm], g)
+            return torch.zeros(n_mol, dtype=e_node.dtype, device=e_node.device).index_add_(0, mol, e_node[:, 0])
+        with torch.enable_grad():
+            pos_g = pos[perm].detach().float().requires_grad_(True)       # graph (Morton) order
+            geometry = ops.edge_geometry(g, lmax=self.net.lmax, pos=pos_g)  # differentiable Y, d, A
+            e_node = self.net(x[perm], g, geometry=geometry)
+            energy = torch.zeros(n_mol, dtype=e_node.dtype, device=e_node.device).index_add(0, mol, e_node[:, 0])
+            (gpos,) = torch.autograd.grad(energy.sum(), pos_g, retain_graph=self.training)
+        f = torch.empty_like(gpos)
+        f[perm] = -gpos
+        return (energy if self.training else energy.detach()), f

@@ -37,9 +37,13 @@ def _hidden_irreps(H: int, lmax: int):
 
 
 def _make_tp(in_irreps, out_irreps, lmax: int):
-    """l_max = 1: the reference operator (pinned).  l_max = 2: its builder-defined generalisation."""
+    """l_max = 1: the reference operator (pinned).  l_max = 2: its builder-defined generalisation -- also used with
+    lmax_sh = 1 for the shapes the reference class rejects (it asserts lmax == 1 on both irreps, l1_tensor_prod.py:13-14,
+    so a scalar-only head such as the 1x0e energy readout cannot be an L1TensorProduct)."""
     if lmax == 1:
-        return L1TensorProduct(in_irreps, out_irreps)
+        if Irreps(in_irreps).lmax == 1 and Irreps(out_irreps).lmax == 1:
+            return L1TensorProduct(in_irreps, out_irreps)
+        return SHTensorProduct(in_irreps, out_irreps, lmax_sh=1)
     return SHTensorProduct(in_irreps, out_irreps, lmax_sh=2)
 
 

@@ -61,5 +61,3 @@ def test_batched_energy_vs_per_molecule_oracle(H):
         out = S.forward_l2(params, H, L, "1x0e+1x1o", "1x0e", x.double().numpy()[ids], pos[ids].astype(np.float64), rp, sc)
         want[m] = out[:, 0].sum()
     assert np.abs(e - want).max() / np.abs(want).max() < 1e-5
-    with pytest.raises(NotImplementedError):
-        model(x.to(DEV), torch.from_numpy(pos).to(DEV), torch.from_numpy(batch).to(DEV), r, forces=True)
