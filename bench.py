@@ -8,10 +8,11 @@
 A "step" is one pass of the hot path over one synthetic batch already resident in HBM:
     Morton sort + cell scan (CSR radius graph)  ->  edge geometry  ->  SEGNN forward (L layers)
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-  roofline     : the dominant kernel (largest total time among the tensor-product launches), timed live
-                 with HIP events on the launch stream; achieved = algorithmic bytes / avg launch time
-  cpu_baseline : the CPU oracle pipeline (reference op pattern for every TP) on a bounded sample,
-                 all host cores, rank 0, N=1 only.
+  roofline     : the dominant kernel (largest total time among the timed launches: the fused message kernel), timed
+                 live with HIP events on the launch stream; achieved = algorithmic flops (x3 for the fp16 split) or bytes
+                 / avg launch time; traffic = HBM bytes per launch from committed rocprofv3 --pmc passes (traffic_source)
+  cpu_baseline : the CPU oracle pipeline (reference op pattern for every TP) on a bounded sample after a warm-up,
+                 all host cores, rank 0, N=1 only; cpu_baseline_best_effort: the best CPU formulation we know.
 """
 import argparse
 import json
@@ -37,7 +38,10 @@ def cutoff(n, k=24.0):
 
 
 def cpu_baseline(args, state):
-    """Oracle pipeline on `--cpu-sample` particles at the same neighbour density."""
+    """CPU pipelines on `--cpu-sample` particles at the same neighbour density, after an untimed warm-up pass:
+    (1) "port": the oracle pipeline with the reference's op pattern for every tensor product (the reported baseline);
+    (2) "best_effort": the same arithmetic in the best CPU formulation we know (contiguous slices, GEMM on raw channels,
+        einsum with the coupling) -- SURVEY.md §8d asks for it so that no ratio is quoted against a strawman."""
     from oracle import graph_oracle as G
     from oracle import segnn_oracle as S
 
@@ -48,24 +52,68 @@ def cpu_baseline(args, state):
         avail = os.cpu_count() or 1
     cores = max(1, min(avail, 16))  # the GPU box's CPU share for one GPU is 16 cores
     torch.set_num_threads(cores)
-    g = torch.Generator().manual_seed(0)
-    pos = torch.rand(n, 3, generator=g).numpy()
-    x = torch.randn(n, 4, generator=torch.Generator().manual_seed(1)).numpy()
-    r = cutoff(n)
     params = {k: v.detach().float().cpu().numpy() for k, v in state.items()}  # CPU baseline always runs in fp32
-    fwd = S.forward_torch_cpu if args.lmax == 1 else S.forward_l2_torch_cpu
-    best = None
-    for _ in range(1):
+    io = ("1x0e+1x1o", "1x1o")
+
+    def port(*a):
+        if args.lmax == 1:
+            return S.forward_torch_cpu(params, args.hidden, args.layers, *io, *a)
+        return S.forward_l2_torch_cpu(params, args.hidden, args.layers, *io, *a)
+
+    def best(*a):
+        return S.forward_l2_torch_cpu(params, args.hidden, args.layers, *io, *a, fast=True, lmax=args.lmax)
+
+    def run(fn, npts):
+        pos = torch.rand(npts, 3, generator=torch.Generator().manual_seed(0)).numpy()
+        x = torch.randn(npts, 4, generator=torch.Generator().manual_seed(1)).numpy()
         t0 = time.perf_counter()
-        perm, rowptr, src = G.graph(pos, [0, 0, 0], [1, 1, 1], r)
+        perm, rowptr, src = G.graph(pos, [0, 0, 0], [1, 1, 1], cutoff(npts))
         with torch.no_grad():
-            fwd(params, args.hidden, args.layers, "1x0e+1x1o", "1x1o", x[perm], pos[perm], rowptr, src)
-        dt = time.perf_counter() - t0
-        best = dt if best is None else min(best, dt)
-    return {"value": n / best, "unit": "particles/s", "cores": cores, "kind": "port",
-            "sample": f"{n} particles, same density (k~24, E={len(src)}), lmax={args.lmax} {args.layers} layers H={args.hidden} fp32; "
-                      f"C cell-list graph (1 thread) + torch-CPU SEGNN with the reference's L1TP op pattern (its l<=2 generalisation when lmax=2; {cores} threads); one timed pass",
-            "seconds": best}
+            fn(x[perm], pos[perm], rowptr, src)
+        return time.perf_counter() - t0, len(src)
+
+    run(port, 1000)  # warm-up: library initialisation, thread pool, first-touch allocations
+    run(best, 1000)
+    dt, E = run(port, n)
+    dtb, _ = run(best, n)
+    desc = (f"{n} particles, same density (k~24, E={E}), lmax={args.lmax} {args.layers} layers H={args.hidden} fp32; "
+            f"C cell-list graph (1 thread) + torch-CPU SEGNN ({cores} threads); one timed pass after a 1000-particle warm-up")
+    return ({"value": n / dt, "unit": "particles/s", "cores": cores, "kind": "port", "seconds": dt,
+             "sample": desc + "; every tensor product in the reference's op pattern (gather -> products -> cat -> matmul -> "
+                              "column scatter -> norm, its l<=2 generalisation when lmax=2)"},
+            {"value": n / dtb, "unit": "particles/s", "cores": cores, "kind": "port", "seconds": dtb,
+             "sample": desc + "; best-effort CPU formulation (contiguous slices, GEMM on raw channels, einsum with the coupling)"})
+
+
+def roofline_of(dom_tag, dom, traffic_file):
+    """roofline object of one timed kernel (profiling.summary() entry)."""
+    sec = dom["avg_ms"] * 1e-3
+    gbs = dom["bytes_per_launch"] / sec / 1e9
+    tfs = dom["flops_per_launch"] / sec / 1e12
+    split = "x3 split" in dom["kernel"]          # fp32 products as 3 f16 MFMA products (hi*hi + hi*lo + lo*hi)
+    native16 = "bf16 storage" in dom["kernel"]
+    mfma_peak = MFMA_BF16_PEAK_TF if (split or native16) else MFMA_F32_PEAK_TF
+    exec_mult = 3.0 if split else 1.0
+    mfma_bound = dom["flops_per_launch"] * exec_mult / (mfma_peak * 1e12) > dom["bytes_per_launch"] / (HBM_PEAK_GBS * 1e9)
+    roof = {"bound": "mfma" if mfma_bound else "hbm", "kernel": dom["kernel"] + "  [" + dom_tag + "]",
+            "achieved": tfs * exec_mult if mfma_bound else gbs, "peak": mfma_peak if mfma_bound else HBM_PEAK_GBS,
+            "unit": "TFLOP/s" if mfma_bound else "GB/s",
+            "frac": (tfs * exec_mult / mfma_peak) if mfma_bound else (gbs / HBM_PEAK_GBS), "traffic": None,
+            "mfma_mode": ("fp16x3 split: one fp32 product = 3 f16 MFMA products (hi*hi + hi*lo + lo*hi), fp32 accumulate; "
+                          "`achieved` = 3 x algorithmic flops / time" if split else
+                          "bf16 operands, fp32 accumulate" if native16 else "fp32"),
+            "frac_on_hbm_roof": gbs / HBM_PEAK_GBS, "frac_on_mfma_roof": tfs * exec_mult / mfma_peak,
+            "avg_launch_ms": dom["avg_ms"], "launches": dom["launches"],
+            "algorithmic_bytes_per_launch": dom["bytes_per_launch"],
+            "algorithmic_flops_per_launch": dom["flops_per_launch"],
+            "algorithmic_GBps": gbs, "algorithmic_TFLOPps": tfs}
+    if traffic_file and os.path.exists(traffic_file):
+        t = json.load(open(traffic_file))
+        roof["traffic"] = t.get("hbm_bytes_per_launch")
+        roof["traffic_source"] = {k: t.get(k) for k in ("file", "commit", "command", "kernel", "fetch_bytes_per_launch",
+                                                        "write_bytes_per_launch", "note")}
+        roof["traffic_source"]["file"] = os.path.relpath(traffic_file, REPO)
+    return roof
 
 
 def main():
@@ -190,51 +238,32 @@ def main():
         m16 = SEGNN("1x0e+1x1o", args.hidden, "1x1o", args.layers, lmax=args.lmax).to(dev)
         m16.load_state_dict(model.state_dict())
         m16 = m16.bfloat16()
-        dt16, _, _, _ = timed(make_step(m16, x.bfloat16()), max(1, args.warmup), args.steps, False)
+        dt16, _, _, prof16 = timed(make_step(m16, x.bfloat16()), max(1, args.warmup), args.steps, True)
         bf16_leg = {"value": n * world / (dt16 / args.steps), "unit": "particles/s", "ms_per_step": dt16 / args.steps * 1e3,
                     "dtype": "bf16", "steps": args.steps,
                     "numerics": "bf16 storage of features/weights/messages, fp32 spherical harmonics, bf16 MFMA with "
                                 "fp32 accumulation (tests/test_bf16_gpu.py: within 1e-2 of the fp64 oracle)"}
+        if rank == 0 and prof16:
+            tag16, dom16 = max(prof16.items(), key=lambda kv: kv[1]["total_ms"])
+            bf16_leg["roofline"] = roofline_of(tag16, dom16, os.path.join(REPO, "profiles", f"r02_traffic_bf16_lmax{args.lmax}.json"))
         del m16
     if rank == 0:
         ms = dt / args.steps * 1e3
         total_particles = n * world
         dom_tag, dom = max(prof.items(), key=lambda kv: kv[1]["total_ms"])
-        sec = dom["avg_ms"] * 1e-3
-        gbs = dom["bytes_per_launch"] / sec / 1e9
-        tfs = dom["flops_per_launch"] / sec / 1e12
-        # the bounding roofline of this kernel = whichever limit gives the longer minimum time
-        # bf16x3 split kernel: every fp32 product is executed as 3 bf16 MFMA products (hi*hi + hi*lo + lo*hi) -> the
-        # matrix pipe sees 3x the algorithmic flops and its peak is the bf16 dense peak
-        split = "x3 split" in dom["kernel"]
-        native16 = "bf16 storage" in dom["kernel"]
-        mfma_peak = MFMA_BF16_PEAK_TF if (split or native16) else MFMA_F32_PEAK_TF
-        exec_mult = 3.0 if split else 1.0
-        mfma_bound = dom["flops_per_launch"] * exec_mult / (mfma_peak * 1e12) > dom["bytes_per_launch"] / (HBM_PEAK_GBS * 1e9)
-        traffic = None
-        tpath = os.path.join(REPO, "profiles", f"r01_traffic_lmax{args.lmax}.json")
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("dominant_kernel_hbm_bytes_per_launch")
-        roof = {"bound": "mfma" if mfma_bound else "hbm", "kernel": dom["kernel"] + "  [" + dom_tag + "]",
-                "achieved": tfs * exec_mult if mfma_bound else gbs, "peak": mfma_peak if mfma_bound else HBM_PEAK_GBS,
-                "unit": "TFLOP/s" if mfma_bound else "GB/s",
-                "frac": (tfs * exec_mult / mfma_peak) if mfma_bound else (gbs / HBM_PEAK_GBS), "traffic": traffic,
-                "mfma_mode": ("fp16x3 split (3 f16 MFMA products per fp32 product: hi*hi + hi*lo + lo*hi, fp32 accumulate)" if split else
-                              "bf16 operands, fp32 accumulate" if native16 else "fp32"),
-                "fp32_equivalent_TFLOPps": tfs, "fp32_equivalent_frac_of_157.3": tfs / MFMA_F32_PEAK_TF,
-                "avg_launch_ms": dom["avg_ms"], "launches": dom["launches"],
-                "algorithmic_bytes_per_launch": dom["bytes_per_launch"],
-                "algorithmic_flops_per_launch": dom["flops_per_launch"],
-                "algorithmic_GBps": gbs, "algorithmic_TFLOPps": tfs,
-                "tp_share_of_step": sum(v["total_ms"] for v in prof.values()) / (dt * 1e3)}
+        roof = roofline_of(dom_tag, dom, os.path.join(REPO, "profiles", f"r02_traffic_lmax{args.lmax}.json"))
+        roof["tp_share_of_step"] = sum(v["total_ms"] for v in prof.values()) / (dt * 1e3)
         if args.timing_json:
             json.dump(prof, open(args.timing_json, "w"), indent=1)
         line = {
             "metric": METRIC, "value": total_particles / (dt / args.steps), "unit": "particles/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "numerics": ("fp32 storage and accumulation; tensor-product contractions as bf16x3-split MFMA "
-                         "(one message TP vs fp64: 5.1e-6 max / 4.1e-6 rms relative, bar 1e-5; E3_TP_EXACT=1 selects exact fp32 MFMA)")
+            "numerics": ("fp32 storage and accumulation; tensor-product contractions as fp16 (hi, lo)-split MFMA with "
+                         "power-of-two operand scales (3 f16 MFMA products per fp32 product, fp32 accumulate): a 4-layer "
+                         "H=32 forward is within 2.5e-7 (l_max=2) / 3.1e-7 (l_max=1) of the fp64 oracle in THIS mode -- "
+                         "tests/test_parity_bench_mode_gpu.py asserts <= 1e-5 (north_star); the exact-fp32 FMA kernels give "
+                         "2.0e-7, the torch-CPU fp32 port 1.8e-7")
                         if args.dtype == "f32" else
                         ("bf16 storage of features/weights/messages, fp32 spherical harmonics, bf16 MFMA with fp32 "
                          "accumulation (one TP within 1e-2 of the fp64 oracle on bf16-rounded inputs)"),
@@ -249,7 +278,7 @@ def main():
         if bf16_leg is not None:
             line["bf16_storage"] = bf16_leg
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args, model.state_dict())
+            line["cpu_baseline"], line["cpu_baseline_best_effort"] = cpu_baseline(args, model.state_dict())
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -284,10 +284,12 @@ int e3_tp_forward_fused_scatter(const e3_tp_plan* plan, const e3_tp_segment* seg
  *   weights: w1[l3] / w2[l3] = the class matrices of TP1 / TP2 for output degree l3 (0e, 1o, 2e), row order and shapes
  *            as e3_tp_weight_shape reports for those irreps (e3_msg_weight_shape returns the same numbers);
  *            n1 / n2 = their norm buffers (length M, 3 M, 5 M) or NULL for 1.
- *   premix : workspace of N * e3_msg_premix_floats_per_node() floats (W_dst h per node, the dst half of TP1)
+ *   premix : N * e3_msg_premix_floats_per_node() floats written by e3_msg_premix (W_dst h per node: the dst half of TP1
+ *            does not depend on the edge, so it is contracted once per NODE and enters the edge kernel as the MFMA
+ *            accumulator's initial value); call e3_msg_premix(h) before e3_msg_forward on the same h and in_scale
  *   out    : [N, ld_out] fp32, columns [H | 3 H | 5 H]; zero-filled by the call unless accumulate != 0
  *   accumulate != 0: a second edge list for the SAME h rows of the dst nodes (e.g. the halo's boundary edges after the
- *            interior ones): out keeps its contents and `premix` must still hold the table the first call wrote
+ *            interior ones): out keeps its contents (premix is reused: it depends on dst rows only)
  *   tiles_per_block: consecutive 16-edge tiles a wave processes before it jumps (0 = a quarter of its workgroup's range)
  * One plan belongs to the device current at its first use.
  * ================================================================================================= */
@@ -299,9 +301,11 @@ int64_t e3_msg_premix_floats_per_node(const e3_msg_plan* plan);
 int e3_msg_weight_shape(const e3_msg_plan* plan, int tp /* 1 | 2 */, int l3, int* rows, int* cols);
 int e3_msg_pack_weights(e3_msg_plan* plan, const float* const w1[3], const float* const n1[3],
                         const float* const w2[3], const float* const n2[3], void* packed, void* stream);
+int e3_msg_premix(e3_msg_plan* plan, const float* h, int64_t ld_h, int64_t N, const void* packed,
+                  const float* in_scale, float* premix, void* stream);
 int e3_msg_forward(e3_msg_plan* plan, const float* h, int64_t ld_h, int64_t N, const float* pos4,
                    const int32_t* src, const int32_t* dst, int64_t E, const void* packed, const float* in_scale,
-                   float* premix, float* out, int64_t ld_out, int accumulate, int tiles_per_block, void* stream);
+                   const float* premix, float* out, int64_t ld_out, int accumulate, int tiles_per_block, void* stream);
 /*
  * bf16 storage (dtype E3_BF16, BASELINE config 3): segments / in1 / out / weights / norms are bf16, in2 (the
  * spherical harmonics) stays fp32, products run once on v_mfma_f32_16x16x32_bf16 with fp32 accumulation and one

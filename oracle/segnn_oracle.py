@@ -163,12 +163,13 @@ def forward_torch_cpu(params, H, num_layers, in_irreps, out_irreps, x, pos, rowp
     return tp("readout", h, A, hid, out_irreps)
 
 
-def forward_l2_torch_cpu(params, H, num_layers, in_irreps, out_irreps, x, pos, rowptr, src):
-    """fp32 torch-CPU l_max = 2 pipeline (bench.py cpu_baseline, kind "port")."""
+def forward_l2_torch_cpu(params, H, num_layers, in_irreps, out_irreps, x, pos, rowptr, src, fast=False, lmax=2):
+    """fp32 torch-CPU l_max = 2 (or 1) pipeline (bench.py cpu_baseline, kind "port").  ``fast``: the tensor products run
+    through ``tp_oracle.forward_torch_cpu_fast`` (best-effort CPU formulation) instead of the reference's op pattern."""
     import torch
     from . import cg, tp_oracle as T
-    hid = f"{H}x0e+{H}x1o+{H}x2e"
-    gated = f"{H}x0e+{2 * H}x0e+{H}x1o+{H}x2e"
+    hid = f"{H}x0e+{H}x1o" + (f"+{H}x2e" if lmax == 2 else "")
+    gated = f"{H}x0e+{lmax * H}x0e+{H}x1o" + (f"+{H}x2e" if lmax == 2 else "")
     rowptr_t, src_t = torch.as_tensor(rowptr).long(), torch.as_tensor(src).long()
     N = rowptr_t.numel() - 1
     deg = rowptr_t[1:] - rowptr_t[:-1]
@@ -176,8 +177,8 @@ def forward_l2_torch_cpu(params, H, num_layers, in_irreps, out_irreps, x, pos, r
     pos = torch.as_tensor(pos, dtype=torch.float32)
     rel = pos[src_t] - pos[dst_t]
     d = rel.norm(dim=1)
-    Y = torch.as_tensor(cg.sh_component(2, rel.numpy()), dtype=torch.float32)
-    A = torch.zeros(N, 9)
+    Y = torch.as_tensor(cg.sh_component(lmax, rel.numpy()), dtype=torch.float32)
+    A = torch.zeros(N, (lmax + 1) ** 2)
     A[:, 0] = 1.0
     A[:, 1:].index_add_(0, dst_t, Y[:, 1:])
     A[:, 1:] /= deg.clamp_min(1)[:, None]
@@ -185,15 +186,18 @@ def forward_l2_torch_cpu(params, H, num_layers, in_irreps, out_irreps, x, pos, r
 
     def tp2(prefix, in1, in2, ii, oi):
         W = {c: P[f"{prefix}.weights_{c}"] for c in T.CLASSES if f"{prefix}.weights_{c}" in P}
-        Nn = {c: P[f"{prefix}.norm_{c}"] for c in T.CLASSES}
-        return T.forward_torch_cpu(ii, oi, 2, in1, in2, W, Nn)
+        Nn = {c: P[f"{prefix}.norm_{c}"] for c in T.CLASSES if f"{prefix}.norm_{c}" in P}
+        for c in T.CLASSES:
+            Nn.setdefault(c, torch.ones(0))
+        return (T.forward_torch_cpu_fast if fast else T.forward_torch_cpu)(ii, oi, lmax, in1, in2, W, Nn)
 
     def g(t):
-        s, g1, g2 = t[:, :H], t[:, H:2 * H], t[:, 2 * H:3 * H]
-        v1 = t[:, 3 * H:6 * H].reshape(-1, H, 3)
-        v2 = t[:, 6 * H:].reshape(-1, H, 5)
-        return torch.cat([torch.nn.functional.silu(s), (torch.sigmoid(g1)[:, :, None] * v1).reshape(-1, 3 * H),
-                          (torch.sigmoid(g2)[:, :, None] * v2).reshape(-1, 5 * H)], 1)
+        out, g0, c0 = [torch.nn.functional.silu(t[:, :H])], H, H + lmax * H
+        for l in range(1, lmax + 1):
+            w = 2 * l + 1
+            out.append((torch.sigmoid(t[:, g0:g0 + H])[:, :, None] * t[:, c0:c0 + H * w].reshape(-1, H, w)).reshape(-1, H * w))
+            g0, c0 = g0 + H, c0 + H * w
+        return torch.cat(out, 1)
 
     h = tp2("embed", torch.as_tensor(x, dtype=torch.float32), A, in_irreps, hid)
     for l in range(num_layers):

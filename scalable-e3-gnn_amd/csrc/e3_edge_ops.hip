@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void edge_geometry_kernel(const float4* __rest
       const float d = sqrtf(rx * rx + ry * ry + rz * rz);
       const float s = d > 0.f ? kSqrt3 / d : 0.f;
       const float4 y = make_float4(1.0f, s * rx, s * ry, s * rz);
-      edge_y[q] = y;
+      if (edge_y) edge_y[q] = y;
       if (edge_d) edge_d[q] = d;
       sx += y.y; sy += y.z; sz += y.w;
     }
@@ -148,9 +148,11 @@ __global__ __launch_bounds__(256) void edge_geometry_l2_kernel(const float4* __r
       Y[6] = s5 * 0.5f * (2.f * z * z - x * x - y * y);
       Y[7] = s5 * kSqrt3 * z * x;
       Y[8] = s5 * 0.5f * kSqrt3 * (x * x - y * y);
-      float* o = edge_y + (int64_t)q * 9;
+      if (edge_y) {
+        float* o = edge_y + (int64_t)q * 9;
 #pragma unroll
-      for (int k = 0; k < 9; ++k) o[k] = Y[k];
+        for (int k = 0; k < 9; ++k) o[k] = Y[k];
+      }
       if (edge_d) edge_d[q] = d;
 #pragma unroll
       for (int k = 0; k < 8; ++k) acc[k] += Y[k + 1];
@@ -231,7 +233,7 @@ int e3_edge_geometry(const float* pos4, const int32_t* rowptr, const int32_t* sr
                      float* edge_d, float* node_a, void* stream) {
   if (N < 0) return E3_ERR_INVALID_ARG;
   if (N == 0) return E3_OK;
-  if (!pos4 || !rowptr || !src || !edge_y) return E3_ERR_INVALID_ARG;
+  if (!pos4 || !rowptr || !src || (!edge_y && !node_a)) return E3_ERR_INVALID_ARG;
   hipLaunchKernelGGL(edge_geometry_kernel, dim3(wave_grid(N)), dim3(256), 0, (hipStream_t)stream,
                      (const float4*)pos4, rowptr, src, N, (float4*)edge_y, edge_d, (float4*)node_a);
   E3_HIP_CHECK(hipGetLastError());
@@ -286,7 +288,7 @@ int e3_edge_geometry_l2(const float* pos4, const int32_t* rowptr, const int32_t*
                         float* edge_d, float* node_a, void* stream) {
   if (N < 0) return E3_ERR_INVALID_ARG;
   if (N == 0) return E3_OK;
-  if (!pos4 || !rowptr || !src || !edge_y) return E3_ERR_INVALID_ARG;
+  if (!pos4 || !rowptr || !src || (!edge_y && !node_a)) return E3_ERR_INVALID_ARG;
   hipLaunchKernelGGL(edge_geometry_l2_kernel, dim3(wave_grid(N)), dim3(256), 0, (hipStream_t)stream,
                      (const float4*)pos4, rowptr, src, N, edge_y, edge_d, node_a);
   E3_HIP_CHECK(hipGetLastError());

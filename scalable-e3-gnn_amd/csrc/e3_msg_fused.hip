@@ -29,6 +29,17 @@
 #include <utility>
 #include <vector>
 
+// development knobs (tools/build_variant.sh builds experiment libraries with other values; the product uses the defaults)
+#ifndef E3_MSG_WD
+#define E3_MSG_WD 1    // weight prefetch distance in blocks (2: 27.1 vs 26.0 ms at 2 waves per SIMD -- registers)
+#endif
+#ifndef E3_MSG_UDP
+#define E3_MSG_UDP 1   // pre-mix prefetch distance in blocks
+#endif
+#ifndef E3_MSG_WPS
+#define E3_MSG_WPS 2   // waves per SIMD the H = 32, l_max = 2 kernel is compiled for (1: 48-55 ms at any prefetch distance)
+#endif
+
 namespace e3 {
 
 #include "e3_tp_mfma_core.h"
@@ -285,6 +296,9 @@ struct TpState {
   uint4 xh[KS][5], xl[KS][5];  // (hi, lo) halves of the current degree's inputs, per component
   uint4 fh[KS], fl[KS];        // feature-first operand of the current degree
   float z[5][5];               // coupling of the current path
+  // operand rings (all indices are compile-time): block IDX reads slot IDX % (D + 1) and requests block IDX + D
+  uint4 wh[E3_MSG_WD + 1][KS], wl[E3_MSG_WD + 1][KS];
+  f32x4 uin[E3_MSG_UDP + 1][5];
 };
 
 // weights of block IDX and, for product #1, its pre-mix values, both requested one block ahead.  (Measured on 1 M
@@ -315,20 +329,19 @@ __device__ __forceinline__ void tp_prefetch_u(const TpCtx& cx, f32x4 (&uin)[5]) 
 template <int LMAX, int TT, bool FIRST, int IDX, class XLOAD>
 __device__ __forceinline__ void tp_block(const TpCtx& cx, const float (&y)[9], XLOAD& xload,
                                          TpState<MsgGeom<LMAX, TT>::KS>& st, f32x4 (&acc0)[MsgGeom<LMAX, TT>::T(0)],
-                                         f32x4 (&acc1)[TT][3], f32x4 (&acc2)[LMAX == 2 ? TT : 1][5],
-                                         const uint4 (&wh)[MsgGeom<LMAX, TT>::KS], const uint4 (&wl)[MsgGeom<LMAX, TT>::KS],
-                                         const f32x4 (&uin)[5]) {
+                                         f32x4 (&acc1)[TT][3], f32x4 (&acc2)[LMAX == 2 ? TT : 1][5]) {
   using G = MsgGeom<LMAX, TT>;
   using BL = BlkList<LMAX, TT>;
   constexpr int KS = G::KS;
   constexpr BlkDesc B = BL::at(IDX);
   constexpr int L1 = B.l1, L2 = B.l2, L3 = B.l3, t = B.t;
   constexpr int D1 = 2 * L1 + 1, D3 = 2 * L3 + 1;
-  // ---- the next block's operands are requested first ----
-  uint4 wh2[KS], wl2[KS];
-  f32x4 nu[5];
-  tp_prefetch_w<LMAX, TT, IDX + 1>(cx, wh2, wl2);
-  tp_prefetch_u<LMAX, TT, FIRST, IDX + 1>(cx, nu);
+  // ---- later blocks' operands are requested first ----
+  tp_prefetch_w<LMAX, TT, IDX + E3_MSG_WD>(cx, st.wh[(IDX + E3_MSG_WD) % (E3_MSG_WD + 1)], st.wl[(IDX + E3_MSG_WD) % (E3_MSG_WD + 1)]);
+  tp_prefetch_u<LMAX, TT, FIRST, IDX + E3_MSG_UDP>(cx, st.uin[(IDX + E3_MSG_UDP) % (E3_MSG_UDP + 1)]);
+  const uint4 (&wh)[KS] = st.wh[IDX % (E3_MSG_WD + 1)];
+  const uint4 (&wl)[KS] = st.wl[IDX % (E3_MSG_WD + 1)];
+  const f32x4 (&uin)[5] = st.uin[IDX % (E3_MSG_UDP + 1)];
   // ---- first block of a degree: inputs, feature-first operand, (hi, lo) halves ----
   if constexpr (B.first_of_l1) {
     float x[KS][8][D1];
@@ -412,7 +425,7 @@ __device__ __forceinline__ void tp_block(const TpCtx& cx, const float (&y)[9], X
         }
   }
   if constexpr (IDX + 1 < BL::count())
-    tp_block<LMAX, TT, FIRST, IDX + 1>(cx, y, xload, st, acc0, acc1, acc2, wh2, wl2, nu);
+    tp_block<LMAX, TT, FIRST, IDX + 1>(cx, y, xload, st, acc0, acc1, acc2);
 }
 
 // One tensor product on the lane's 16-edge tile.  XLOAD(l1tag, ks, x[8][D1]) delivers the (scaled) fp32 inputs of this
@@ -423,11 +436,16 @@ __device__ __forceinline__ void tp_core(const TpCtx& cx, const float (&y)[9], XL
                                         f32x4 (&acc2)[LMAX == 2 ? TT : 1][5]) {
   constexpr int KS = MsgGeom<LMAX, TT>::KS;
   TpState<KS> st;
-  uint4 wh[KS], wl[KS];
-  f32x4 uin[5];
-  tp_prefetch_w<LMAX, TT, 0>(cx, wh, wl);
-  tp_prefetch_u<LMAX, TT, FIRST, 0>(cx, uin);
-  tp_block<LMAX, TT, FIRST, 0>(cx, y, xload, st, acc0, acc1, acc2, wh, wl, uin);
+  // prologue of the rings: blocks 0 .. D - 1
+  auto prime = [&](auto itag) {
+    constexpr int I = decltype(itag)::value;
+    if constexpr (I < E3_MSG_WD) tp_prefetch_w<LMAX, TT, I>(cx, st.wh[I % (E3_MSG_WD + 1)], st.wl[I % (E3_MSG_WD + 1)]);
+    if constexpr (I < E3_MSG_UDP) tp_prefetch_u<LMAX, TT, FIRST, I>(cx, st.uin[I % (E3_MSG_UDP + 1)]);
+  };
+  prime(std::integral_constant<int, 0>{}); prime(std::integral_constant<int, 1>{});
+  prime(std::integral_constant<int, 2>{}); prime(std::integral_constant<int, 3>{});
+  static_assert(E3_MSG_WD <= 4 && E3_MSG_UDP <= 4, "ring prologue");
+  tp_block<LMAX, TT, FIRST, 0>(cx, y, xload, st, acc0, acc1, acc2);
 }
 
 // real "component" spherical harmonics of the edge vector (same expressions as edge_geometry_l2_kernel, e3_edge_ops.hip)
@@ -555,7 +573,9 @@ __global__ __launch_bounds__(256) void msg_premix_kernel(const float* __restrict
 // ------------------------------------------------------------------------------------------------------------------
 // the edge kernel
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int msg_waves_per_simd(int lmax, int tt) { return (lmax == 2 ? 44 : 20) * tt <= 96 ? 2 : 1; }
+constexpr int msg_waves_per_simd(int lmax, int tt) {
+  return (lmax == 2 ? 44 : 20) * tt <= 96 ? ((lmax == 2 && tt == 2) ? E3_MSG_WPS : 2) : 1;
+}
 
 template <int LMAX, int TT>
 __global__ __launch_bounds__(256, msg_waves_per_simd(LMAX, TT)) void msg_fused_kernel(
@@ -623,11 +643,17 @@ __global__ __launch_bounds__(256, msg_waves_per_simd(LMAX, TT)) void msg_fused_k
     s_ = src[e];
     d_ = dst[e];
   };
-  for (int64_t b0 = wg_lo + (int64_t)wave * blk; b0 < wg_hi; b0 += 4 * (int64_t)blk) {
+  // outer = blocks of `blk` consecutive tiles dealt round-robin to the four waves, inner = the tiles of a block.
+  // (A workgroup barrier per tile, so that the waves share one weight stream through L1, measured 26.9 vs 26.5 ms.)
+  const int64_t n_outer = (tiles_per_wg + 4 * (int64_t)blk - 1) / (4 * (int64_t)blk);
+  for (int64_t ob = 0; ob < n_outer; ++ob) {
+    const int64_t b0 = wg_lo + (ob * 4 + wave) * blk;
     const int64_t b1 = b0 + blk < wg_hi ? b0 + blk : wg_hi;
     int sid_n = 0, did_n = 0;
-    load_ids(b0, sid_n, did_n);
-    for (int64_t tile = b0; tile < b1; ++tile) {
+    if (b0 < b1) load_ids(b0, sid_n, did_n);
+    for (int64_t ti = 0; ti < blk; ++ti) {
+      const int64_t tile = b0 + ti;
+      if (tile >= b1) break;
       const int64_t row0 = tile * 16;
       const int nrows = (int)((E - row0) < 16 ? (E - row0) : 16);
       const int sid = sid_n, did = did_n;
@@ -1056,8 +1082,24 @@ int e3_msg_pack_weights(e3_msg_plan* P, const float* const w1[3], const float* c
   return E3_OK;
 }
 
+int e3_msg_premix(e3_msg_plan* P, const float* h, int64_t ld_h, int64_t N, const void* packed, const float* in_scale,
+                  float* premix, void* stream) {
+  if (!P || N < 0) return E3_ERR_INVALID_ARG;
+  const MsgKernels& k = *P->k;
+  if (N == 0) return E3_OK;
+  if (!h || !packed || !premix || ld_h < k.D) return E3_ERR_INVALID_ARG;
+  if ((ld_h & 3) || ((uintptr_t)h & 15) || ((uintptr_t)premix & 15)) return E3_ERR_INVALID_ARG;  // 16-byte row accesses
+  int st = msg_ensure_device(P);
+  if (st != E3_OK) return st;
+  const int64_t ntiles = (N + 15) / 16;
+  const int grid = (int)std::min<int64_t>((ntiles + 3) / 4, 2048);
+  void* args[] = {&h, &ld_h, &N, &packed, &in_scale, &premix};
+  if (hipLaunchKernel(k.premix, dim3(grid), dim3(256), args, 0, (hipStream_t)stream) != hipSuccess) return E3_ERR_HIP;
+  return E3_OK;
+}
+
 int e3_msg_forward(e3_msg_plan* P, const float* h, int64_t ld_h, int64_t N, const float* pos4, const int32_t* src,
-                   const int32_t* dst, int64_t E, const void* packed, const float* in_scale, float* premix,
+                   const int32_t* dst, int64_t E, const void* packed, const float* in_scale, const float* premix,
                    float* out, int64_t ld_out, int accumulate, int tiles_per_block, void* stream) {
   if (!P || N < 0 || E < 0) return E3_ERR_INVALID_ARG;
   const MsgKernels& k = *P->k;
@@ -1069,15 +1111,8 @@ int e3_msg_forward(e3_msg_plan* P, const float* h, int64_t ld_h, int64_t N, cons
   if (st != E3_OK) return st;
   hipStream_t s = (hipStream_t)stream;
   // out is an accumulation target of atomics: the rows start from zero unless this launch continues an earlier one
-  // (accumulate != 0: same h rows of every dst node, so the pre-mix table of that launch is reused as well)
   if (!accumulate) E3_HIP_CHECK(hipMemset2DAsync(out, (size_t)ld_out * 4, 0, (size_t)k.D * 4, (size_t)N, s));
   if (E == 0) return E3_OK;
-  if (!accumulate) {
-    const int64_t ntiles = (N + 15) / 16;
-    const int grid = (int)std::min<int64_t>((ntiles + 3) / 4, 2048);
-    void* args[] = {&h, &ld_h, &N, &packed, &in_scale, &premix};
-    if (hipLaunchKernel(k.premix, dim3(grid), dim3(256), args, 0, s) != hipSuccess) return E3_ERR_HIP;
-  }
   const int64_t ntiles = (E + 15) / 16;
   int nwg = 256 * k.waves_per_simd;  // 4 waves per workgroup; waves_per_simd workgroups per CU
   nwg = (int)std::min<int64_t>(nwg, (ntiles + 3) / 4);

@@ -126,9 +126,19 @@ class FusedMessage:
                 from . import ops
                 in_scale = ops.pow2_scale([h])
             hd = self._plans.handle(dev)
-            premix = cont[1] if cont is not None else torch.empty(N * int(lib.e3_msg_premix_floats_per_node(hd)),
-                                                                  dtype=torch.float32, device=dev)
             stream = torch.cuda.current_stream(dev).cuda_stream
+            ud = int(lib.e3_msg_premix_floats_per_node(hd))
+            if cont is not None:
+                premix = cont[1]
+            else:
+                premix = torch.empty(N * ud, dtype=torch.float32, device=dev)
+                t0 = profiling.begin() if profiling.enabled() else None
+                _lib.check(lib.e3_msg_premix(hd, h.data_ptr(), h.stride(0), N, packed.data_ptr(), in_scale.data_ptr(),
+                                             premix.data_ptr(), stream), "e3_msg_premix")
+                if t0 is not None:
+                    # node-level GEMM h [N, (l_max+1)^2 H] x W_dst: reads h, writes the table
+                    profiling.end(f"msg_premix lmax={self.lmax} H={self.hidden} N={N}", N, 4 * N * (W + ud), t0,
+                                  flops=2 * self.hidden * ud * N, kernel="e3::msg_premix_kernel<fp16x3 split MFMA>")
             t0 = profiling.begin() if profiling.enabled() else None
             _lib.check(lib.e3_msg_forward(hd, h.data_ptr(), h.stride(0), N, g.pos4.data_ptr(), src.data_ptr(),
                                           dst.data_ptr(), E, packed.data_ptr(), in_scale.data_ptr(), premix.data_ptr(),
@@ -138,7 +148,6 @@ class FusedMessage:
                 # algorithmic bytes: h read once, positions, the two index columns, aggregated rows written once
                 nb = 4 * N * W + 16 * N + 8 * E + 4 * N * W
                 profiling.end(f"msg_fused lmax={self.lmax} H={self.hidden} E={E}", E, nb, t0,
-                              flops=self.flops_per_edge() * E,
-                              kernel="e3::msg_fused_kernel (+ e3::msg_premix_kernel)<fp16x3 split MFMA>")
+                              flops=self.flops_per_edge() * E, kernel="e3::msg_fused_kernel<fp16x3 split MFMA>")
         self.last_state = (out, premix)
         return out

@@ -25,17 +25,18 @@ def _wants_grad(*ts) -> bool:
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts)
 
 
-def _edge_geometry_raw(pos4, g, want_dist, want_node_attr, lmax):
+def _edge_geometry_raw(pos4, g, want_dist, want_node_attr, lmax, want_edge=True):
     N, E, dev = g.rowptr.numel() - 1, g.num_edges, pos4.device
     ny = (lmax + 1) ** 2
-    Y = torch.empty((E, ny), dtype=torch.float32, device=dev)
-    d = torch.empty(E, dtype=torch.float32, device=dev) if want_dist else None
+    Y = torch.empty((E, ny), dtype=torch.float32, device=dev) if want_edge else None
+    d = torch.empty(E, dtype=torch.float32, device=dev) if (want_dist and want_edge) else None
     A = torch.empty((N, ny), dtype=torch.float32, device=dev) if want_node_attr else None
     fn = {1: "e3_edge_geometry", 2: "e3_edge_geometry_l2"}[lmax]
     with torch.cuda.device(dev):
         _lib.check(getattr(_lib.load(), fn)(pos4.data_ptr(), g.rowptr.data_ptr(), g.src.data_ptr(), N,
-                                                Y.data_ptr(), d.data_ptr() if d is not None else None,
-                                                A.data_ptr() if A is not None else None, _stream(Y)),
+                                                Y.data_ptr() if Y is not None else None,
+                                                d.data_ptr() if d is not None else None,
+                                                A.data_ptr() if A is not None else None, _stream(pos4)),
                    "e3_edge_geometry")
     return Y, d, A
 
@@ -68,8 +69,10 @@ class _EdgeGeometryFn(torch.autograd.Function):
         return gpos, None, None
 
 
-def edge_geometry(g: RadiusGraph, want_dist=True, want_node_attr=True, lmax: int = 1, pos: torch.Tensor | None = None):
-    """-> Y [E,(lmax+1)^2], d [E] | None, A [N,(lmax+1)^2] | None.
+def edge_geometry(g: RadiusGraph, want_dist=True, want_node_attr=True, lmax: int = 1, pos: torch.Tensor | None = None,
+                  want_edge=True):
+    """-> Y [E,(lmax+1)^2] | None, d [E] | None, A [N,(lmax+1)^2] | None.  ``want_edge=False``: only the node attribute
+    (the fused message kernel computes the spherical harmonics of its edges itself).
 
     ``pos`` [N,3] (graph order, i.e. ``original_pos[g.perm]``): when given and it requires grad, the three outputs are
     differentiable w.r.t. it (forces = -dE/dpos); otherwise the graph's own ``pos4`` is used."""
@@ -81,7 +84,7 @@ def edge_geometry(g: RadiusGraph, want_dist=True, want_node_attr=True, lmax: int
     if pos is not None:
         pos4 = torch.zeros_like(g.pos4)
         pos4[:, :3] = pos
-    return _edge_geometry_raw(pos4, g, want_dist, want_node_attr, lmax)
+    return _edge_geometry_raw(pos4, g, want_dist, want_node_attr, lmax, want_edge)
 
 
 class _GatherConcatFn(torch.autograd.Function):

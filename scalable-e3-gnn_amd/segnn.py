@@ -153,7 +153,13 @@ class SEGNN(nn.Module):
         interior / boundary lists so that the refresh overlaps the interior edges."""
         if split is not None:
             g = split.graph
-        Y, d, A = geometry if geometry is not None else ops.edge_geometry(g, lmax=self.lmax)
+        if geometry is not None:
+            Y, d, A = geometry
+        else:
+            # per-edge Y [E, (l_max+1)^2] and d [E] are only needed off the one-launch message path
+            one_launch = (x.dtype == torch.float32 and not (torch.is_grad_enabled() and _needs_grad(self, x)) and
+                          all(l.fused and l.fuse_message and l.fuse_scatter and l._msg is not None for l in self.layers))
+            Y, d, A = ops.edge_geometry(g, lmax=self.lmax, want_edge=not one_launch)
         if x.dtype == torch.bfloat16 and self.lmax != 2:
             raise RuntimeError("bf16 storage is implemented for l_max = 2 (BASELINE config 3)")
         h = self.embed(x, A)

@@ -108,3 +108,40 @@ def test_state_dict_roundtrip_and_deepcopy():
     mod.load_state_dict(sd, strict=True)
     mod2 = copy.deepcopy(mod)
     assert all(torch.equal(a, b) for a, b in zip(mod.state_dict().values(), mod2.state_dict().values()))
+
+
+def test_modules_deepcopy_and_pickle_without_sharing_plan_handles():
+    """plan handles are ctypes pointers; modules must still deep-copy / pickle (EMA copies, torch.save of a
+    whole module) and two copies must never own the same handle."""
+    import copy
+    import pickle
+
+    from scalable_e3_gnn_amd.segnn import SEGNN
+
+    m = SEGNN("1x0e+1x1o", 32, "1x1o", 2, lmax=2)
+    m.layers[0].msg1._plan.handle(None)            # a host-side handle exists
+    c = copy.deepcopy(m)
+    assert c.layers[0].msg1._plan is not m.layers[0].msg1._plan
+    assert c.layers[0].msg1._plan._plans._handles == {} or \
+        c.layers[0].msg1._plan._plans._handles[-1].value != m.layers[0].msg1._plan._plans._handles[-1].value
+    assert c.layers[0]._msg is not m.layers[0]._msg
+    p = pickle.loads(pickle.dumps(m))
+    assert sorted(p.state_dict()) == sorted(m.state_dict())
+    l1 = SEGNN("1x0e+1x1o", 32, "1x1o", 1, lmax=1)
+    l1.layers[0].msg1._get_plan().handle(None)
+    c1 = copy.deepcopy(l1)
+    assert c1.layers[0].msg1._plan is not l1.layers[0].msg1._plan
+
+
+def test_fused_availability_does_not_depend_on_first_call_grad_mode():
+    """the cached part of the fused-path decision is static; grad mode is looked at on every call."""
+    import torch
+
+    from scalable_e3_gnn_amd.segnn import SEGNNLayer
+
+    layer = SEGNNLayer(32, 2)
+    with torch.enable_grad():
+        a = layer.fused_available()
+    with torch.no_grad():
+        b = layer.fused_available()
+    assert a == b == SEGNNLayer(32, 2).fused_available()
