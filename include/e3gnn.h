@@ -277,8 +277,10 @@ int e3_tp_forward_fused_scatter(const e3_tp_plan* plan, const e3_tp_segment* seg
  * e3_edge_geometry / e3_edge_geometry_l2), TP1 / TP2 = e3_tp_* products with in irreps Hx0e+Hx1o(+Hx2e) (TP1: twice that
  * plus 1x0e) and out irreps Hx0e + lmax*H x0e + Hx1o (+Hx2e), gate = [silu(s) | sigmoid(g_l) v_l].  One launch (plus a
  * per-node pre-mix launch) per layer: neither Y [E, 9], d [E] nor any [E, width] message tensor exists in HBM.
- * hidden in {16, 32, 64}; fp32 storage; fp16 (hi, lo)-split MFMA products (see "Operand scales"; `in_scale` = scale of
- * h, NULL = 1; the gated messages between the two products are scaled per edge row inside the kernel).
+ * hidden in {16, 32, 64}.  dtype E3_F32: fp32 storage, fp16 (hi, lo)-split MFMA products (see "Operand scales"; `in_scale` =
+ * scale of h, NULL = 1; the gated messages between the two products are scaled per edge row inside the kernel).
+ * dtype E3_BF16 (hidden 32 / 64; e3_msg_supports): h, weights and norms bf16, positions / harmonics / accumulators / the
+ * pre-mix table / `out` fp32, one bf16 MFMA per product, the messages between the two products rounded to bf16.
  * Edges must be sorted by dst (CSR order, as e3_rg_fill emits them): runs of equal dst are summed on chip and leave as
  * one fp32 atomic add per node and wave -- sums agree with e3_segment_sum to fp32 rounding, not bit for bit.
  *   weights: w1[l3] / w2[l3] = the class matrices of TP1 / TP2 for output degree l3 (0e, 1o, 2e), row order and shapes
@@ -299,13 +301,15 @@ int e3_msg_plan_destroy(e3_msg_plan* plan);
 int64_t e3_msg_packed_bytes(const e3_msg_plan* plan);
 int64_t e3_msg_premix_floats_per_node(const e3_msg_plan* plan);
 int e3_msg_weight_shape(const e3_msg_plan* plan, int tp /* 1 | 2 */, int l3, int* rows, int* cols);
-int e3_msg_pack_weights(e3_msg_plan* plan, const float* const w1[3], const float* const n1[3],
-                        const float* const w2[3], const float* const n2[3], void* packed, void* stream);
-int e3_msg_premix(e3_msg_plan* plan, const float* h, int64_t ld_h, int64_t N, const void* packed,
-                  const float* in_scale, float* premix, void* stream);
-int e3_msg_forward(e3_msg_plan* plan, const float* h, int64_t ld_h, int64_t N, const float* pos4,
+int e3_msg_supports(const e3_msg_plan* plan, int dtype);
+int e3_msg_pack_weights(e3_msg_plan* plan, const void* const w1[3], const void* const n1[3],
+                        const void* const w2[3], const void* const n2[3], int dtype, void* packed, void* stream);
+int e3_msg_premix(e3_msg_plan* plan, const void* h, int64_t ld_h, int64_t N, const void* packed,
+                  const float* in_scale, float* premix, int dtype, void* stream);
+int e3_msg_forward(e3_msg_plan* plan, const void* h, int64_t ld_h, int64_t N, const float* pos4,
                    const int32_t* src, const int32_t* dst, int64_t E, const void* packed, const float* in_scale,
-                   const float* premix, float* out, int64_t ld_out, int accumulate, int tiles_per_block, void* stream);
+                   const float* premix, float* out, int64_t ld_out, int dtype, int accumulate, int tiles_per_block,
+                   void* stream);
 /*
  * bf16 storage (dtype E3_BF16, BASELINE config 3): segments / in1 / out / weights / norms are bf16, in2 (the
  * spherical harmonics) stays fp32, products run once on v_mfma_f32_16x16x32_bf16 with fp32 accumulation and one

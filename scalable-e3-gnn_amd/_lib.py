@@ -66,10 +66,12 @@ SIGNATURES = {
     "e3_msg_packed_bytes": (c_int64, [c_void_p]),
     "e3_msg_premix_floats_per_node": (c_int64, [c_void_p]),
     "e3_msg_weight_shape": (c_int, [c_void_p, c_int, c_int, POINTER(c_int), POINTER(c_int)]),
-    "e3_msg_pack_weights": (c_int, [c_void_p, c_void_p * 3, c_void_p * 3, c_void_p * 3, c_void_p * 3, c_void_p, c_void_p]),
-    "e3_msg_premix": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "e3_msg_supports": (c_int, [c_void_p, c_int]),
+    "e3_msg_pack_weights": (c_int, [c_void_p, c_void_p * 3, c_void_p * 3, c_void_p * 3, c_void_p * 3, c_int, c_void_p,
+                                    c_void_p]),
+    "e3_msg_premix": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "e3_msg_forward": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
-                               c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+                               c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     "e3_edge_geometry_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_void_p]),
     "e3_gather_concat_backward": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64,

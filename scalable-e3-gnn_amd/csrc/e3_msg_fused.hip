@@ -113,22 +113,22 @@ struct MsgPackDesc {  // one weight block
   int blk;            // block index inside the role
 };
 struct MsgPackArgs {
-  const float* w1[3];
-  const float* w2[3];
-  const float* n1[3];
-  const float* n2[3];
+  const void* w1[3];
+  const void* w2[3];
+  const void* n1[3];
+  const void* n2[3];
   int64_t nw1[3], nw2[3];  // elements per class matrix
   int rowd[3];             // row of the distance channel in class l's matrix (path (0, l, l)), TP #1
   int M0, H, LMAX, TT, NS, WD, o_norm1, o_norm2, o_wd, o_w, nblk;
 };
 
-__global__ void msg_absmax_kernel(MsgPackArgs a, uint32_t* hdr) {
+__global__ void msg_absmax_kernel(MsgPackArgs a, uint32_t* hdr) {  // fp32 storage only
   float m1 = 0.f, m2 = 0.f;
   for (int c = 0; c < 3; ++c) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < a.nw1[c]; i += (int64_t)gridDim.x * blockDim.x)
-      m1 = fmaxf(m1, fabsf(a.w1[c][i]));
+      m1 = fmaxf(m1, fabsf(static_cast<const float*>(a.w1[c])[i]));
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < a.nw2[c]; i += (int64_t)gridDim.x * blockDim.x)
-      m2 = fmaxf(m2, fabsf(a.w2[c][i]));
+      m2 = fmaxf(m2, fabsf(static_cast<const float*>(a.w2[c])[i]));
   }
   for (int o = 32; o > 0; o >>= 1) { m1 = fmaxf(m1, __shfl_xor(m1, o)); m2 = fmaxf(m2, __shfl_xor(m2, o)); }
   if ((threadIdx.x & 63) == 0) {
@@ -137,23 +137,32 @@ __global__ void msg_absmax_kernel(MsgPackArgs a, uint32_t* hdr) {
   }
 }
 
+// T = float: fp16 (hi, lo) halves of w * sw.  T = bf16 (bf16 storage): the bf16 weights themselves in the hi half, sw = 1.
+template <typename T>
 __global__ void msg_pack_kernel(MsgPackArgs a, const MsgPackDesc* desc, int ndesc, float* packed) {
+  constexpr bool IO16 = std::is_same<T, bf16>::value;
   const uint32_t* hb = reinterpret_cast<const uint32_t*>(packed);
-  const float sw1 = pow2_scale_from_bits(hb[0], 13), sw2 = pow2_scale_from_bits(hb[3], 13);
+  const float sw1 = IO16 ? 1.0f : pow2_scale_from_bits(hb[0], 13), sw2 = IO16 ? 1.0f : pow2_scale_from_bits(hb[3], 13);
+  auto rd = [](const void* p, int64_t i) { return to_acc(static_cast<const T*>(p)[i]); };
   for (int r = blockIdx.x; r < ndesc; r += gridDim.x) {
     const MsgPackDesc q = desc[r];
-    const float* W = q.role == 1 ? a.w2[q.mat] : a.w1[q.mat];
+    const void* W = q.role == 1 ? a.w2[q.mat] : a.w1[q.mat];
     const float sw = q.role == 1 ? sw2 : sw1;
     uint16_t* dst = reinterpret_cast<uint16_t*>(packed + a.o_w + ((size_t)q.role * a.nblk + q.blk) * 512);
     for (int i = threadIdx.x; i < 512; i += blockDim.x) {
       const int lane = i >> 3, jj = i & 7, ch = lane & 15, g = lane >> 4;
       const int k = kperm(g, jj);
       float v = 0.f;
-      if (k < q.nvalid && q.colbase + ch < q.M) v = W[(int64_t)(q.rowbase + k) * q.M + q.colbase + ch] * sw;
-      const _Float16 hi = (_Float16)v;
-      const _Float16 lo = (_Float16)(v - (float)hi);
-      dst[lane * 8 + jj] = __builtin_bit_cast(uint16_t, hi);
-      dst[512 + lane * 8 + jj] = __builtin_bit_cast(uint16_t, lo);
+      if (k < q.nvalid && q.colbase + ch < q.M) v = rd(W, (int64_t)(q.rowbase + k) * q.M + q.colbase + ch) * sw;
+      if constexpr (IO16) {
+        dst[lane * 8 + jj] = __builtin_bit_cast(uint16_t, (__bf16)v);
+        dst[512 + lane * 8 + jj] = 0;
+      } else {
+        const _Float16 hi = (_Float16)v;
+        const _Float16 lo = (_Float16)(v - (float)hi);
+        dst[lane * 8 + jj] = __builtin_bit_cast(uint16_t, hi);
+        dst[512 + lane * 8 + jj] = __builtin_bit_cast(uint16_t, lo);
+      }
     }
   }
   if (blockIdx.x == 0) {
@@ -166,8 +175,8 @@ __global__ void msg_pack_kernel(MsgPackArgs a, const MsgPackDesc* desc, int ndes
       else if (s < T0 + 3 * a.TT) { l3 = 1; t = (s - T0) / 3; c = (s - T0) % 3; }
       else { l3 = 2; t = (s - T0 - 3 * a.TT) / 5; c = (s - T0 - 3 * a.TT) % 5; }
       const int idx = (16 * t + ch) * (2 * l3 + 1) + c;
-      packed[a.o_norm1 + i] = (a.n1[l3] ? a.n1[l3][idx] : 1.0f) / sw1;
-      packed[a.o_norm2 + i] = (a.n2[l3] ? a.n2[l3][idx] : 1.0f) / sw2;
+      packed[a.o_norm1 + i] = (a.n1[l3] ? rd(a.n1[l3], idx) : 1.0f) / sw1;
+      packed[a.o_norm2 + i] = (a.n2[l3] ? rd(a.n2[l3], idx) : 1.0f) / sw2;
     }
     for (int i = threadIdx.x; i < a.WD; i += blockDim.x) {
       const int T0 = a.TT * (1 + a.LMAX);
@@ -176,7 +185,7 @@ __global__ void msg_pack_kernel(MsgPackArgs a, const MsgPackDesc* desc, int ndes
       else if (i < (T0 + a.TT) * 16) { l = 1; rem = i - T0 * 16; }
       else { l = 2; rem = i - (T0 + a.TT) * 16; }
       const int M = l == 0 ? a.M0 : a.H;
-      packed[a.o_wd + i] = a.w1[l][(int64_t)a.rowd[l] * M + rem] * sw1;
+      packed[a.o_wd + i] = rd(a.w1[l], (int64_t)a.rowd[l] * M + rem) * sw1;
     }
     if (threadIdx.x == 0) {
       packed[1] = sw1; packed[2] = 1.0f / sw1;
@@ -213,18 +222,28 @@ __host__ __device__ constexpr bool z_nonzero(int a, int c) {
   return false;
 }
 
-// three f16 MFMAs = one fp32-grade product group
+// one product group: fp32 storage = three f16 MFMAs on (hi, lo) halves (fp32-grade), bf16 storage = one bf16 MFMA
+template <bool IO16>
 __device__ __forceinline__ f32x4 mma3(const uint4 ah, const uint4 al, const uint4 bh, const uint4 bl, f32x4 c) {
-  c = mfma16h(__builtin_bit_cast(f16x8, ah), __builtin_bit_cast(f16x8, bh), c);
-  c = mfma16h(__builtin_bit_cast(f16x8, ah), __builtin_bit_cast(f16x8, bl), c);
-  c = mfma16h(__builtin_bit_cast(f16x8, al), __builtin_bit_cast(f16x8, bh), c);
-  return c;
+  if constexpr (IO16) {
+    return mfma16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bh), c);
+  } else {
+    c = mfma16h(__builtin_bit_cast(f16x8, ah), __builtin_bit_cast(f16x8, bh), c);
+    c = mfma16h(__builtin_bit_cast(f16x8, ah), __builtin_bit_cast(f16x8, bl), c);
+    c = mfma16h(__builtin_bit_cast(f16x8, al), __builtin_bit_cast(f16x8, bh), c);
+    return c;
+  }
 }
 
+// 8 fp32 values -> B operand(s): fp16 (hi, lo), or bf16 rounded once (exact when the values came from bf16 storage)
+template <bool IO16>
 __device__ __forceinline__ void split8(const float (&f)[8], uint4& bh, uint4& bl) {
-  uint32_t ph[4], pl[4];
+  uint32_t ph[4], pl[4] = {0, 0, 0, 0};
 #pragma unroll
-  for (int q = 0; q < 4; ++q) split2_f16(f[2 * q], f[2 * q + 1], ph[q], pl[q]);
+  for (int q = 0; q < 4; ++q) {
+    if constexpr (IO16) ph[q] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{f[2 * q], f[2 * q + 1]}, bf16x2_t));
+    else split2_f16(f[2 * q], f[2 * q + 1], ph[q], pl[q]);
+  }
   bh = uint4{ph[0], ph[1], ph[2], ph[3]};
   bl = uint4{pl[0], pl[1], pl[2], pl[3]};
 }
@@ -242,12 +261,49 @@ struct TpCtx {
 
 // A operand of one weight block: buffer load = descriptor (SGPRs) + scalar block offset + this lane's 32-bit offset, so
 // the ~70 block addresses of a product cost no vector registers and no 64-bit address arithmetic
+template <bool IO16>
 __device__ __forceinline__ void load_w(const TpCtx& cx, const int blk, uint4& hi, uint4& lo) {
   const uint32_t so = cx.wrole + (uint32_t)blk * 2048u;
   const u32x4 h = __builtin_amdgcn_raw_buffer_load_b128(cx.w, cx.woff, so, 0);
-  const u32x4 l = __builtin_amdgcn_raw_buffer_load_b128(cx.w, cx.woff + 1024u, so, 0);
   hi = uint4{h[0], h[1], h[2], h[3]};
-  lo = uint4{l[0], l[1], l[2], l[3]};
+  if constexpr (!IO16) {
+    const u32x4 l = __builtin_amdgcn_raw_buffer_load_b128(cx.w, cx.woff + 1024u, so, 0);
+    lo = uint4{l[0], l[1], l[2], l[3]};
+  }
+}
+
+// 4 consecutive channels x D1 components of a feature row (channel-major, component-minor) -> x[4 p + r][a], scaled.
+// fp32 storage: D1 16-byte reads; bf16 storage: D1 8-byte reads, widened (exact).  `piece` points at channel 0 of the 4.
+template <int D1, bool IO16>
+__device__ __forceinline__ void read_piece(const void* piece, const int p, const float xs, float (&x)[8][D1]) {
+  float q[4 * D1];
+  if constexpr (IO16) {
+    const uint2* sp = reinterpret_cast<const uint2*>(piece);
+#pragma unroll
+    for (int u = 0; u < D1; ++u) {
+      const uint2 v = sp[u];
+      q[4 * u + 0] = __builtin_bit_cast(float, v.x << 16); q[4 * u + 1] = __builtin_bit_cast(float, v.x & 0xffff0000u);
+      q[4 * u + 2] = __builtin_bit_cast(float, v.y << 16); q[4 * u + 3] = __builtin_bit_cast(float, v.y & 0xffff0000u);
+    }
+  } else {
+    const float4* sp = reinterpret_cast<const float4*>(piece);
+#pragma unroll
+    for (int u = 0; u < D1; ++u) {
+      const float4 v = sp[u];
+      q[4 * u] = v.x * xs; q[4 * u + 1] = v.y * xs; q[4 * u + 2] = v.z * xs; q[4 * u + 3] = v.w * xs;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int a = 0; a < D1; ++a) x[4 * p + r][a] = q[r * D1 + a];
+}
+template <int D1>
+__device__ __forceinline__ void zero_piece(const int p, float (&x)[8][D1]) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int a = 0; a < D1; ++a) x[4 * p + r][a] = 0.f;
 }
 
 // ---- one tensor product as a flat, software-pipelined list of blocks ----------------------------------------------
@@ -304,7 +360,7 @@ struct TpState {
 // weights of block IDX and, for product #1, its pre-mix values, both requested one block ahead.  (Measured on 1 M
 // particles: a weight prefetch distance of two blocks costs 8 registers -> spills -> 27.1 vs 26.0 ms; touching the
 // pre-mix rows of the tile's dst nodes ahead of product #1 (L2 warm-up) 25.9 vs 26.2 ms: neither is kept.)
-template <int LMAX, int TT, int IDX>
+template <int LMAX, int TT, bool IO16, int IDX>
 __device__ __forceinline__ void tp_prefetch_w(const TpCtx& cx, uint4 (&wh)[MsgGeom<LMAX, TT>::KS],
                                               uint4 (&wl)[MsgGeom<LMAX, TT>::KS]) {
   using G = MsgGeom<LMAX, TT>;
@@ -312,7 +368,7 @@ __device__ __forceinline__ void tp_prefetch_w(const TpCtx& cx, uint4 (&wh)[MsgGe
     constexpr BlkDesc B = BlkList<LMAX, TT>::at(IDX);
     constexpr int T = G::T(B.l3), B0 = G::blk(B.l1, B.l2, B.l3);
 #pragma unroll
-    for (int ks = 0; ks < G::KS; ++ks) load_w(cx, B0 + ks * T + B.t, wh[ks], wl[ks]);
+    for (int ks = 0; ks < G::KS; ++ks) load_w<IO16>(cx, B0 + ks * T + B.t, wh[ks], wl[ks]);
   }
 }
 template <int LMAX, int TT, bool FIRST, int IDX>
@@ -326,7 +382,7 @@ __device__ __forceinline__ void tp_prefetch_u(const TpCtx& cx, f32x4 (&uin)[5]) 
   }
 }
 
-template <int LMAX, int TT, bool FIRST, int IDX, class XLOAD>
+template <int LMAX, int TT, bool FIRST, bool IO16, int IDX, class XLOAD>
 __device__ __forceinline__ void tp_block(const TpCtx& cx, const float (&y)[9], XLOAD& xload,
                                          TpState<MsgGeom<LMAX, TT>::KS>& st, f32x4 (&acc0)[MsgGeom<LMAX, TT>::T(0)],
                                          f32x4 (&acc1)[TT][3], f32x4 (&acc2)[LMAX == 2 ? TT : 1][5]) {
@@ -337,7 +393,7 @@ __device__ __forceinline__ void tp_block(const TpCtx& cx, const float (&y)[9], X
   constexpr int L1 = B.l1, L2 = B.l2, L3 = B.l3, t = B.t;
   constexpr int D1 = 2 * L1 + 1, D3 = 2 * L3 + 1;
   // ---- later blocks' operands are requested first ----
-  tp_prefetch_w<LMAX, TT, IDX + E3_MSG_WD>(cx, st.wh[(IDX + E3_MSG_WD) % (E3_MSG_WD + 1)], st.wl[(IDX + E3_MSG_WD) % (E3_MSG_WD + 1)]);
+  tp_prefetch_w<LMAX, TT, IO16, IDX + E3_MSG_WD>(cx, st.wh[(IDX + E3_MSG_WD) % (E3_MSG_WD + 1)], st.wl[(IDX + E3_MSG_WD) % (E3_MSG_WD + 1)]);
   tp_prefetch_u<LMAX, TT, FIRST, IDX + E3_MSG_UDP>(cx, st.uin[(IDX + E3_MSG_UDP) % (E3_MSG_UDP + 1)]);
   const uint4 (&wh)[KS] = st.wh[IDX % (E3_MSG_WD + 1)];
   const uint4 (&wl)[KS] = st.wl[IDX % (E3_MSG_WD + 1)];
@@ -362,7 +418,7 @@ __device__ __forceinline__ void tp_block(const TpCtx& cx, const float (&y)[9], X
           for (int a = 1; a < D1; ++a) sum = __builtin_fmaf(zz[a][0], x[ks][i][a], sum);
           f[i] = sum;
         }
-        split8(f, st.fh[ks], st.fl[ks]);
+        split8<IO16>(f, st.fh[ks], st.fl[ks]);
       }
     }
 #pragma unroll
@@ -372,7 +428,7 @@ __device__ __forceinline__ void tp_block(const TpCtx& cx, const float (&y)[9], X
         float f[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) f[i] = x[ks][i][a];
-        split8(f, st.xh[ks][a], st.xl[ks][a]);
+        split8<IO16>(f, st.xh[ks][a], st.xl[ks][a]);
       }
   }
   if constexpr (B.first_of_path && !B.ff) {
@@ -387,7 +443,7 @@ __device__ __forceinline__ void tp_block(const TpCtx& cx, const float (&y)[9], X
   if constexpr (B.ff) {
     f32x4 o = acc0[t];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) o = mma3(wh[ks], wl[ks], st.fh[ks], st.fl[ks], o);
+    for (int ks = 0; ks < KS; ++ks) o = mma3<IO16>(wh[ks], wl[ks], st.fh[ks], st.fl[ks], o);
     if constexpr (FIRST) {  // dst half: fold of the per-node pre-mix
 #pragma unroll
       for (int a = 0; a < D1; ++a)
@@ -410,7 +466,7 @@ __device__ __forceinline__ void tp_block(const TpCtx& cx, const float (&y)[9], X
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-      for (int a = 0; a < D1; ++a) u[a] = mma3(wh[ks], wl[ks], st.xh[ks][a], st.xl[ks][a], u[a]);
+      for (int a = 0; a < D1; ++a) u[a] = mma3<IO16>(wh[ks], wl[ks], st.xh[ks][a], st.xl[ks][a], u[a]);
 #pragma unroll
     for (int c = 0; c < D3; ++c)
 #pragma unroll
@@ -425,12 +481,12 @@ __device__ __forceinline__ void tp_block(const TpCtx& cx, const float (&y)[9], X
         }
   }
   if constexpr (IDX + 1 < BL::count())
-    tp_block<LMAX, TT, FIRST, IDX + 1>(cx, y, xload, st, acc0, acc1, acc2);
+    tp_block<LMAX, TT, FIRST, IO16, IDX + 1>(cx, y, xload, st, acc0, acc1, acc2);
 }
 
 // One tensor product on the lane's 16-edge tile.  XLOAD(l1tag, ks, x[8][D1]) delivers the (scaled) fp32 inputs of this
 // lane: x[jj][a] = channel 32 ks + kperm(g, jj), component a.  acc0 / acc1 / acc2: output tiles per degree.
-template <int LMAX, int TT, bool FIRST, class XLOAD>
+template <int LMAX, int TT, bool FIRST, bool IO16, class XLOAD>
 __device__ __forceinline__ void tp_core(const TpCtx& cx, const float (&y)[9], XLOAD&& xload,
                                         f32x4 (&acc0)[MsgGeom<LMAX, TT>::T(0)], f32x4 (&acc1)[TT][3],
                                         f32x4 (&acc2)[LMAX == 2 ? TT : 1][5]) {
@@ -439,13 +495,13 @@ __device__ __forceinline__ void tp_core(const TpCtx& cx, const float (&y)[9], XL
   // prologue of the rings: blocks 0 .. D - 1
   auto prime = [&](auto itag) {
     constexpr int I = decltype(itag)::value;
-    if constexpr (I < E3_MSG_WD) tp_prefetch_w<LMAX, TT, I>(cx, st.wh[I % (E3_MSG_WD + 1)], st.wl[I % (E3_MSG_WD + 1)]);
+    if constexpr (I < E3_MSG_WD) tp_prefetch_w<LMAX, TT, IO16, I>(cx, st.wh[I % (E3_MSG_WD + 1)], st.wl[I % (E3_MSG_WD + 1)]);
     if constexpr (I < E3_MSG_UDP) tp_prefetch_u<LMAX, TT, FIRST, I>(cx, st.uin[I % (E3_MSG_UDP + 1)]);
   };
   prime(std::integral_constant<int, 0>{}); prime(std::integral_constant<int, 1>{});
   prime(std::integral_constant<int, 2>{}); prime(std::integral_constant<int, 3>{});
   static_assert(E3_MSG_WD <= 4 && E3_MSG_UDP <= 4, "ring prologue");
-  tp_block<LMAX, TT, FIRST, 0>(cx, y, xload, st, acc0, acc1, acc2);
+  tp_block<LMAX, TT, FIRST, IO16, 0>(cx, y, xload, st, acc0, acc1, acc2);
 }
 
 // real "component" spherical harmonics of the edge vector (same expressions as edge_geometry_l2_kernel, e3_edge_ops.hip)
@@ -479,15 +535,16 @@ __device__ __forceinline__ void edge_sh1(const float4 ps, const float4 pd, float
 // pre-mix: U[n] = (W_dst * sw) (h[n] * xs) for every path of TP #1, in the layout the edge kernel reads as accumulator
 // initial values.  One wave per 16 nodes; inputs straight from global memory (each lane reads its own k slots).
 // ------------------------------------------------------------------------------------------------------------------
-template <int LMAX, int TT>
-__global__ __launch_bounds__(256) void msg_premix_kernel(const float* __restrict__ h, int64_t ldh, int64_t N,
+template <int LMAX, int TT, bool IO16>
+__global__ __launch_bounds__(256) void msg_premix_kernel(const void* __restrict__ hv, int64_t ldh, int64_t N,
                                                          const float* __restrict__ packed,
                                                          const float* __restrict__ in_scale, float* __restrict__ U) {
   using G = MsgGeom<LMAX, TT>;
+  constexpr int ES = IO16 ? 2 : 4;
   const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
   const int64_t wave0 = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
   const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  const float xs = in_scale ? in_scale[0] : 1.0f;
+  const float xs = (!IO16 && in_scale) ? in_scale[0] : 1.0f;
   TpCtx cx;
   cx.w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(packed + G::o_w), 0, 3 * G::nblk() * 2048, 0x00020000);
   cx.wrole = 2 * G::nblk() * 2048;  // role 2
@@ -496,7 +553,7 @@ __global__ __launch_bounds__(256) void msg_premix_kernel(const float* __restrict
   for (int64_t tile = wave0; tile < ntiles; tile += nw) {
     const int64_t n = tile * 16 + j;
     const bool ok = n < N;
-    const float* row = h + (ok ? n : N - 1) * ldh;
+    const char* row = reinterpret_cast<const char*>(hv) + (ok ? n : N - 1) * ldh * ES;
     float* urow = U + (ok ? n : N - 1) * (int64_t)G::UD + 4 * g;
     auto per_l1 = [&](auto l1tag) {
       constexpr int L1 = decltype(l1tag)::value, D1 = 2 * L1 + 1;
@@ -506,32 +563,17 @@ __global__ __launch_bounds__(256) void msg_premix_kernel(const float* __restrict
         float x[8][D1];
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-          const int ch0 = 32 * ks + 16 * p + 4 * g;
-          if (16 * (2 * ks + p) < G::H) {
-            const float4* src = reinterpret_cast<const float4*>(row + G::col0(L1) + ch0 * D1);
-            float q[4 * D1];
-#pragma unroll
-            for (int u = 0; u < D1; ++u) {
-              const float4 v = src[u];
-              q[4 * u] = v.x; q[4 * u + 1] = v.y; q[4 * u + 2] = v.z; q[4 * u + 3] = v.w;
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-              for (int a = 0; a < D1; ++a) x[4 * p + r][a] = q[r * D1 + a] * xs;
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-              for (int a = 0; a < D1; ++a) x[4 * p + r][a] = 0.f;
-          }
+          if (16 * (2 * ks + p) < G::H)
+            read_piece<D1, IO16>(row + (G::col0(L1) + (32 * ks + 16 * p + 4 * g) * D1) * ES, p, xs, x);
+          else
+            zero_piece<D1>(p, x);
         }
 #pragma unroll
         for (int a = 0; a < D1; ++a) {
           float f[8];
 #pragma unroll
           for (int i = 0; i < 8; ++i) f[i] = x[i][a];
-          split8(f, xh[ks][a], xl[ks][a]);
+          split8<IO16>(f, xh[ks][a], xl[ks][a]);
         }
       }
       auto per_path = [&](auto l2tag, auto l3tag) {
@@ -546,9 +588,9 @@ __global__ __launch_bounds__(256) void msg_premix_kernel(const float* __restrict
 #pragma unroll
             for (int ks = 0; ks < G::KS; ++ks) {
               uint4 ah, al;
-              load_w(cx, B0 + ks * T + t, ah, al);
+              load_w<IO16>(cx, B0 + ks * T + t, ah, al);
 #pragma unroll
-              for (int a = 0; a < D1; ++a) u[a] = mma3(ah, al, xh[ks][a], xl[ks][a], u[a]);
+              for (int a = 0; a < D1; ++a) u[a] = mma3<IO16>(ah, al, xh[ks][a], xl[ks][a], u[a]);
             }
             if (ok) {
 #pragma unroll
@@ -577,9 +619,9 @@ constexpr int msg_waves_per_simd(int lmax, int tt) {
   return (lmax == 2 ? 44 : 20) * tt <= 96 ? ((lmax == 2 && tt == 2) ? E3_MSG_WPS : 2) : 1;
 }
 
-template <int LMAX, int TT>
+template <int LMAX, int TT, bool IO16>
 __global__ __launch_bounds__(256, msg_waves_per_simd(LMAX, TT)) void msg_fused_kernel(
-    const float* __restrict__ h, int64_t ldh, const float4* __restrict__ pos4, const int32_t* __restrict__ src,
+    const void* __restrict__ hv, int64_t ldh, const float4* __restrict__ pos4, const int32_t* __restrict__ src,
     const int32_t* __restrict__ dst, int64_t E, const float* __restrict__ packed, const float* __restrict__ U,
     const float* __restrict__ in_scale, float* __restrict__ out, int64_t ldo, int64_t tiles_per_wg, int blk) {
   using G = MsgGeom<LMAX, TT>;
@@ -595,7 +637,10 @@ __global__ __launch_bounds__(256, msg_waves_per_simd(LMAX, TT)) void msg_fused_k
   float* n2tab = n1tab + NS * 16;
   float* wdtab = n2tab + NS * 16;
   float* wbuf = wdtab + G::WD + (size_t)wave * G::lds_wave;
-  const float xs = in_scale ? in_scale[0] : 1.0f, ixs = in_scale ? in_scale[1] : 1.0f;
+  // bf16 storage needs no operand scales (bf16 has the fp32 exponent range): xs = 1, messages unscaled
+  constexpr int ES = IO16 ? 2 : 4;  // bytes per stored feature element
+  const char* h = reinterpret_cast<const char*>(hv);
+  const float xs = (!IO16 && in_scale) ? in_scale[0] : 1.0f, ixs = (!IO16 && in_scale) ? in_scale[1] : 1.0f;
   for (int i = tid; i < NS * 16; i += blockDim.x) {
     n1tab[i] = packed[G::o_norm1 + i] * ixs;
     n2tab[i] = packed[G::o_norm2 + i];
@@ -674,35 +719,38 @@ __global__ __launch_bounds__(256, msg_waves_per_simd(LMAX, TT)) void msg_fused_k
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       wave_sync_lds();
       {
-        auto stage_region = [&](auto utag, auto otag, float* dstf) {
-          constexpr int UNITS = decltype(utag)::value, SRCOFF = decltype(otag)::value;  // units per row, first source float
+        auto stage_region = [&](auto utag, auto otag, char* dstb) {
+          constexpr int UNITS = decltype(utag)::value, SRCOFF = decltype(otag)::value;  // units per row, first source element
           if constexpr (UNITS >= 64) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const int rid = __builtin_amdgcn_readlane(sid, r);
-              const float* rowp = h + (int64_t)rid * ldh + SRCOFF;
+              const char* rowp = h + ((int64_t)rid * ldh + SRCOFF) * ES;
 #pragma unroll
               for (int k = 0; k < UNITS / 64; ++k)
-                __builtin_amdgcn_global_load_lds((glb_void_t*)(rowp + (k * 64 + lane) * 4),
-                                                 (lds_void_t*)(dstf + (r * UNITS + k * 64) * 4), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((glb_void_t*)(rowp + (k * 64 + lane) * 16),
+                                                 (lds_void_t*)(dstb + (r * UNITS + k * 64) * 16), 16, 0, 0);
             }
           } else {
             constexpr int RPI = 64 / UNITS;  // rows per instruction
+            static_assert(RPI <= 16, "region rows shorter than 4 units are not supported");
             const int u = lane & (UNITS - 1), rl = lane / UNITS;
             int rid[16 / RPI];  // all shuffles first: they are LDS-pipe instructions, and hipcc guards every LDS access
 #pragma unroll                  // behind an LDS-DMA in flight with vmcnt(0), which would serialise the copies
             for (int it = 0; it < 16 / RPI; ++it) rid[it] = __shfl(sid, it * RPI + rl);
 #pragma unroll
             for (int it = 0; it < 16 / RPI; ++it)
-              __builtin_amdgcn_global_load_lds((glb_void_t*)(h + (int64_t)rid[it] * ldh + SRCOFF + u * 4),
-                                               (lds_void_t*)(dstf + it * 256), 16, 0, 0);
+              __builtin_amdgcn_global_load_lds((glb_void_t*)(h + ((int64_t)rid[it] * ldh + SRCOFF) * ES + u * 16),
+                                               (lds_void_t*)(dstb + it * 1024), 16, 0, 0);
           }
         };
+        // element counts per row: l_max 2: A = [1o | 2e] = 8 H, B = [0e] = H; l_max 1: 4 H
+        char* wb = reinterpret_cast<char*>(wbuf);
         if constexpr (LMAX == 2) {
-          stage_region(std::integral_constant<int, 2 * H>{}, std::integral_constant<int, H>{}, wbuf);
-          stage_region(std::integral_constant<int, H / 4>{}, std::integral_constant<int, 0>{}, wbuf + 16 * 8 * H);
+          stage_region(std::integral_constant<int, 8 * H * ES / 16>{}, std::integral_constant<int, H>{}, wb);
+          stage_region(std::integral_constant<int, H * ES / 16>{}, std::integral_constant<int, 0>{}, wb + 16 * 8 * H * ES);
         } else {
-          stage_region(std::integral_constant<int, H>{}, std::integral_constant<int, 0>{}, wbuf);
+          stage_region(std::integral_constant<int, 4 * H * ES / 16>{}, std::integral_constant<int, 0>{}, wb);
         }
       }
       // ---- geometry while the copies fly ----
@@ -738,32 +786,17 @@ __global__ __launch_bounds__(256, msg_waves_per_simd(LMAX, TT)) void msg_fused_k
         cx.dsc = dist * xs;
         auto xload = [&](auto l1tag, int ks, auto& x) {
           constexpr int L1 = decltype(l1tag)::value, D1 = 2 * L1 + 1;
-          // first float of degree L1 in this lane's staged row (see the LDS image above)
-          const float* xrow = LMAX == 2 ? (L1 == 0 ? wbuf + 16 * 8 * H + j * H : wbuf + j * 8 * H + (L1 == 1 ? 0 : 3 * H))
-                                        : wbuf + j * 4 * H + (L1 == 0 ? 0 : H);
+          // first element of degree L1 in this lane's staged row (see the LDS image above), in elements
+          const int e0 = LMAX == 2 ? (L1 == 0 ? 16 * 8 * H + j * H : j * 8 * H + (L1 == 1 ? 0 : 3 * H))
+                                   : j * 4 * H + (L1 == 0 ? 0 : H);
+          const char* xrow = reinterpret_cast<const char*>(wbuf) + e0 * ES;
 #pragma unroll
           for (int p = 0; p < 2; ++p) {
-            if (16 * (2 * ks + p) < H) {
-              const float4* sp = reinterpret_cast<const float4*>(xrow + (32 * ks + 16 * p + 4 * g) * D1);
-              float q[4 * D1];
-#pragma unroll
-              for (int u = 0; u < D1; ++u) {
-                const float4 v = sp[u];
-                q[4 * u] = v.x; q[4 * u + 1] = v.y; q[4 * u + 2] = v.z; q[4 * u + 3] = v.w;
-              }
-#pragma unroll
-              for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int a = 0; a < D1; ++a) x[4 * p + r][a] = q[r * D1 + a] * xs;
-            } else {
-#pragma unroll
-              for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int a = 0; a < D1; ++a) x[4 * p + r][a] = 0.f;
-            }
+            if (16 * (2 * ks + p) < H) read_piece<D1, IO16>(xrow + (32 * ks + 16 * p + 4 * g) * D1 * ES, p, xs, x);
+            else zero_piece<D1>(p, x);
           }
         };
-        tp_core<LMAX, TT, true>(cx, y, xload, a0, a1, a2);
+        tp_core<LMAX, TT, true, IO16>(cx, y, xload, a0, a1, a2);
       }
 
       // ---- gate #1; the messages stay in accumulator layout = the B-operand layout of product #2 ----
@@ -805,16 +838,27 @@ __global__ __launch_bounds__(256, msg_waves_per_simd(LMAX, TT)) void msg_fused_k
         gate_block(std::integral_constant<int, 3>{}, a1, G::slot0(1), TT);
         if constexpr (LMAX == 2) gate_block(std::integral_constant<int, 5>{}, a2, G::slot0(2), 2 * TT);
       }
-      amax = fmaxf(amax, __shfl_xor(amax, 16));
-      amax = fmaxf(amax, __shfl_xor(amax, 32));
-      const float srow = pow2_scale_from_bits(__builtin_bit_cast(uint32_t, amax), 10);
-      const float isrow = 1.0f / srow;
+      float srow = 1.0f, isrow = 1.0f;
+      if constexpr (!IO16) {
+        amax = fmaxf(amax, __shfl_xor(amax, 16));
+        amax = fmaxf(amax, __shfl_xor(amax, 32));
+        srow = pow2_scale_from_bits(__builtin_bit_cast(uint32_t, amax), 10);
+        isrow = 1.0f / srow;
+      }
 
       // ---- park the (scaled) messages: slot q of lane l at wbuf[(q * 64 + l) * 4] ----
       wave_sync_lds();
       {
         f32x4* pk = reinterpret_cast<f32x4*>(wbuf) + lane;
-        auto sc4 = [&](const f32x4 v) { return f32x4{v[0] * srow, v[1] * srow, v[2] * srow, v[3] * srow}; };
+        auto sc4 = [&](const f32x4 v) {
+          if constexpr (IO16) {  // bf16 storage: the messages between the two products are bf16 values
+            f32x4 o;
+            for (int r = 0; r < 4; ++r) o[r] = (float)(__bf16)v[r];
+            return o;
+          } else {
+            return f32x4{v[0] * srow, v[1] * srow, v[2] * srow, v[3] * srow};
+          }
+        };
 #pragma unroll
         for (int t = 0; t < TT; ++t) pk[64 * t] = sc4(a0[t]);
 #pragma unroll
@@ -860,7 +904,7 @@ __global__ __launch_bounds__(256, msg_waves_per_simd(LMAX, TT)) void msg_fused_k
             }
           }
         };
-        tp_core<LMAX, TT, false>(cx, y, xload, a0, a1, a2);
+        tp_core<LMAX, TT, false, IO16>(cx, y, xload, a0, a1, a2);
       }
 
       // ---- gate #2, then the segment sum: the whole gated tile goes to LDS as [row][output column] (the accumulators are
@@ -931,17 +975,23 @@ __global__ __launch_bounds__(256, msg_waves_per_simd(LMAX, TT)) void msg_fused_k
 // ------------------------------------------------------------------------------------------------------------------
 struct MsgKernels {
   int lmax, tt;
-  const void* fused;
-  const void* premix;
+  const void* fused[2];   // [0] fp32 storage, [1] bf16 storage (nullptr: not instantiated)
+  const void* premix[2];
   int64_t total_floats;
   int UD, D, lds_tab, lds_wave, nblk, NS, WD, o_norm1, o_norm2, o_wd, o_w, waves_per_simd;
 };
 template <int LMAX, int TT>
 static MsgKernels make_entry() {
   using G = MsgGeom<LMAX, TT>;
-  return {LMAX, TT, (const void*)msg_fused_kernel<LMAX, TT>, (const void*)msg_premix_kernel<LMAX, TT>, G::total_floats,
-          G::UD, G::D, G::lds_tab, G::lds_wave, G::nblk(), G::NS, G::WD, G::o_norm1, G::o_norm2, G::o_wd, G::o_w,
-          msg_waves_per_simd(LMAX, TT)};
+  MsgKernels k = {LMAX, TT, {(const void*)msg_fused_kernel<LMAX, TT, false>, nullptr},
+                  {(const void*)msg_premix_kernel<LMAX, TT, false>, nullptr}, G::total_floats,
+                  G::UD, G::D, G::lds_tab, G::lds_wave, G::nblk(), G::NS, G::WD, G::o_norm1, G::o_norm2, G::o_wd, G::o_w,
+                  msg_waves_per_simd(LMAX, TT)};
+  if constexpr (TT >= 2) {  // bf16 storage: the [0e] region of a staged row must be at least 4 units of 16 bytes (H >= 32)
+    k.fused[1] = (const void*)msg_fused_kernel<LMAX, TT, true>;
+    k.premix[1] = (const void*)msg_premix_kernel<LMAX, TT, true>;
+  }
+  return k;
 }
 static const std::vector<MsgKernels>& msg_kernels() {
   static const std::vector<MsgKernels> k = {make_entry<2, 2>(), make_entry<1, 2>(), make_entry<2, 1>(), make_entry<1, 1>(),
@@ -976,10 +1026,12 @@ static int msg_ensure_device(e3_msg_plan* P) {
     return E3_ERR_HIP;
   }
   const size_t lds = (size_t)(P->k->lds_tab + 4 * P->k->lds_wave) * 4;
-  if (hipFuncSetAttribute(P->k->fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-    (void)hipFree(d);
-    return E3_ERR_HIP;
-  }
+  for (int io = 0; io < 2; ++io)
+    if (P->k->fused[io] &&
+        hipFuncSetAttribute(P->k->fused[io], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      (void)hipFree(d);
+      return E3_ERR_HIP;
+    }
   P->device = cur;
   P->d_desc = d;
   return E3_OK;
@@ -1054,9 +1106,15 @@ int e3_msg_weight_shape(const e3_msg_plan* P, int tp, int l3, int* rows, int* co
   return E3_OK;
 }
 
-int e3_msg_pack_weights(e3_msg_plan* P, const float* const w1[3], const float* const n1[3], const float* const w2[3],
-                        const float* const n2[3], void* packed, void* stream) {
+int e3_msg_supports(const e3_msg_plan* P, int dtype) {
+  if (!P) return 0;
+  return dtype == E3_F32 ? 1 : (dtype == E3_BF16 && P->k->fused[1] != nullptr) ? 1 : 0;
+}
+
+int e3_msg_pack_weights(e3_msg_plan* P, const void* const w1[3], const void* const n1[3], const void* const w2[3],
+                        const void* const n2[3], int dtype, void* packed, void* stream) {
   if (!P || !w1 || !w2 || !packed) return E3_ERR_INVALID_ARG;
+  if (!e3_msg_supports(P, dtype)) return E3_ERR_UNSUPPORTED;
   for (int l = 0; l <= P->lmax; ++l)
     if (!w1[l] || !w2[l]) return E3_ERR_MISSING_WEIGHT;
   int st = msg_ensure_device(P);
@@ -1075,38 +1133,46 @@ int e3_msg_pack_weights(e3_msg_plan* P, const float* const w1[3], const float* c
   a.o_norm1 = k.o_norm1; a.o_norm2 = k.o_norm2; a.o_wd = k.o_wd; a.o_w = k.o_w; a.nblk = k.nblk;
   hipStream_t s = (hipStream_t)stream;
   E3_HIP_CHECK(hipMemsetAsync(packed, 0, 256, s));
-  hipLaunchKernelGGL(msg_absmax_kernel, dim3(64), dim3(256), 0, s, a, (uint32_t*)packed);
-  hipLaunchKernelGGL(msg_pack_kernel, dim3(std::min<int>((int)P->desc.size(), 512)), dim3(256), 0, s, a, P->d_desc,
-                     (int)P->desc.size(), (float*)packed);
+  const dim3 grid(std::min<int>((int)P->desc.size(), 512));
+  if (dtype == E3_F32) {
+    hipLaunchKernelGGL(msg_absmax_kernel, dim3(64), dim3(256), 0, s, a, (uint32_t*)packed);
+    hipLaunchKernelGGL(msg_pack_kernel<float>, grid, dim3(256), 0, s, a, P->d_desc, (int)P->desc.size(), (float*)packed);
+  } else {
+    hipLaunchKernelGGL(msg_pack_kernel<bf16>, grid, dim3(256), 0, s, a, P->d_desc, (int)P->desc.size(), (float*)packed);
+  }
   E3_HIP_CHECK(hipGetLastError());
   return E3_OK;
 }
 
-int e3_msg_premix(e3_msg_plan* P, const float* h, int64_t ld_h, int64_t N, const void* packed, const float* in_scale,
-                  float* premix, void* stream) {
+int e3_msg_premix(e3_msg_plan* P, const void* h, int64_t ld_h, int64_t N, const void* packed, const float* in_scale,
+                  float* premix, int dtype, void* stream) {
   if (!P || N < 0) return E3_ERR_INVALID_ARG;
+  if (!e3_msg_supports(P, dtype)) return E3_ERR_UNSUPPORTED;
   const MsgKernels& k = *P->k;
+  const int io = dtype == E3_BF16 ? 1 : 0, es = io ? 2 : 4;
   if (N == 0) return E3_OK;
   if (!h || !packed || !premix || ld_h < k.D) return E3_ERR_INVALID_ARG;
-  if ((ld_h & 3) || ((uintptr_t)h & 15) || ((uintptr_t)premix & 15)) return E3_ERR_INVALID_ARG;  // 16-byte row accesses
+  if ((ld_h * es & 15) || ((uintptr_t)h & 15) || ((uintptr_t)premix & 15)) return E3_ERR_INVALID_ARG;  // 16-byte row accesses
   int st = msg_ensure_device(P);
   if (st != E3_OK) return st;
   const int64_t ntiles = (N + 15) / 16;
   const int grid = (int)std::min<int64_t>((ntiles + 3) / 4, 2048);
   void* args[] = {&h, &ld_h, &N, &packed, &in_scale, &premix};
-  if (hipLaunchKernel(k.premix, dim3(grid), dim3(256), args, 0, (hipStream_t)stream) != hipSuccess) return E3_ERR_HIP;
+  if (hipLaunchKernel(k.premix[io], dim3(grid), dim3(256), args, 0, (hipStream_t)stream) != hipSuccess) return E3_ERR_HIP;
   return E3_OK;
 }
 
-int e3_msg_forward(e3_msg_plan* P, const float* h, int64_t ld_h, int64_t N, const float* pos4, const int32_t* src,
+int e3_msg_forward(e3_msg_plan* P, const void* h, int64_t ld_h, int64_t N, const float* pos4, const int32_t* src,
                    const int32_t* dst, int64_t E, const void* packed, const float* in_scale, const float* premix,
-                   float* out, int64_t ld_out, int accumulate, int tiles_per_block, void* stream) {
+                   float* out, int64_t ld_out, int dtype, int accumulate, int tiles_per_block, void* stream) {
   if (!P || N < 0 || E < 0) return E3_ERR_INVALID_ARG;
+  if (!e3_msg_supports(P, dtype)) return E3_ERR_UNSUPPORTED;
   const MsgKernels& k = *P->k;
+  const int io = dtype == E3_BF16 ? 1 : 0, es = io ? 2 : 4;
   if (N == 0) return E3_OK;
   if (!h || !pos4 || !packed || !premix || !out || ld_h < k.D || ld_out < k.D || (E > 0 && (!src || !dst)))
     return E3_ERR_INVALID_ARG;
-  if ((ld_h & 3) || ((uintptr_t)h & 15) || ((uintptr_t)premix & 15)) return E3_ERR_INVALID_ARG;  // 16-byte row gathers
+  if ((ld_h * es & 15) || ((uintptr_t)h & 15) || ((uintptr_t)premix & 15)) return E3_ERR_INVALID_ARG;  // 16-byte row gathers
   int st = msg_ensure_device(P);
   if (st != E3_OK) return st;
   hipStream_t s = (hipStream_t)stream;
@@ -1123,7 +1189,7 @@ int e3_msg_forward(e3_msg_plan* P, const float* h, int64_t ld_h, int64_t N, cons
   const size_t lds = (size_t)(k.lds_tab + 4 * k.lds_wave) * 4;
   void* args[] = {&h, &ld_h, &pos4, &src, &dst, &E, &packed, &premix, &in_scale, &out, &ld_out,
                   const_cast<int64_t*>(&tiles_per_wg), &blk};
-  if (hipLaunchKernel(k.fused, dim3(nwg), dim3(256), args, lds, s) != hipSuccess) return E3_ERR_HIP;
+  if (hipLaunchKernel(k.fused[io], dim3(nwg), dim3(256), args, lds, s) != hipSuccess) return E3_ERR_HIP;
   return E3_OK;
 }
 

@@ -46,13 +46,18 @@ class FusedMessage:
         ns = [getattr(tp, "norm_" + c, None) for c in _NAT]
         return ws, ns
 
-    def packed(self, msg1, msg2, device) -> torch.Tensor:
+    def supports(self, dtype) -> bool:
+        if dtype == torch.float32:
+            return True
+        return dtype == torch.bfloat16 and bool(_lib.load().e3_msg_supports(self._plans.handle(None), _lib.E3_BF16))
+
+    def packed(self, msg1, msg2, device, dtype=torch.float32) -> torch.Tensor:
         lib = _lib.load()
         w1, n1 = self._tensors(msg1)
         w2, n2 = self._tensors(msg2)
         ts = w1 + n1 + w2 + n2
         key = tuple((t.data_ptr(), t._version) if t is not None else None for t in ts)
-        hit = self._packed.get(device)
+        hit = self._packed.get((device, dtype))
         stream = torch.cuda.current_stream(device)
         if hit is not None and hit[0] == key:
             if hit[2] != stream.cuda_stream:
@@ -64,8 +69,8 @@ class FusedMessage:
                 rows, cols = ctypes.c_int(), ctypes.c_int()
                 lib.e3_msg_weight_shape(h, tpi, l, ctypes.byref(rows), ctypes.byref(cols))
                 w = ws[l]
-                if w is None or tuple(w.shape) != (rows.value, cols.value) or w.dtype != torch.float32 or w.device != device:
-                    raise RuntimeError(f"fused message: TP #{tpi} weights of degree {l} must be float32 "
+                if w is None or tuple(w.shape) != (rows.value, cols.value) or w.dtype != dtype or w.device != device:
+                    raise RuntimeError(f"fused message: TP #{tpi} weights of degree {l} must be {dtype} "
                                        f"[{rows.value}, {cols.value}] on {device}, got "
                                        f"{None if w is None else (tuple(w.shape), w.dtype, w.device)}")
         P3 = ctypes.c_void_p * 3
@@ -73,12 +78,15 @@ class FusedMessage:
         ptr = lambda t: t.data_ptr() if (t is not None and t.numel()) else None
         packed = torch.empty(int(lib.e3_msg_packed_bytes(h)), dtype=torch.uint8, device=device)
         with torch.cuda.device(device):
+            for t in keep[3:6] + keep[9:12]:
+                if t is not None and t.numel() and t.dtype != dtype:
+                    raise RuntimeError(f"fused message: norm buffers must be {dtype} (cast the module), got {t.dtype}")
             _lib.check(lib.e3_msg_pack_weights(h, P3(*map(ptr, keep[0:3])), P3(*map(ptr, keep[3:6])),
-                                               P3(*map(ptr, keep[6:9])), P3(*map(ptr, keep[9:12])), packed.data_ptr(),
-                                               stream.cuda_stream), "e3_msg_pack_weights")
+                                               P3(*map(ptr, keep[6:9])), P3(*map(ptr, keep[9:12])), _lib.dtype_code(dtype),
+                                               packed.data_ptr(), stream.cuda_stream), "e3_msg_pack_weights")
         ev = torch.cuda.Event()
         ev.record(stream)
-        self._packed[device] = (key, packed, stream.cuda_stream, ev)
+        self._packed[(device, dtype)] = (key, packed, stream.cuda_stream, ev)
         return packed
 
     def flops_per_edge(self) -> int:
@@ -96,17 +104,20 @@ class FusedMessage:
 
     def forward(self, h: torch.Tensor, g: RadiusGraph, msg1, msg2, in_scale: torch.Tensor | None = None, edges=None,
                 cont=None):
-        """h [N, width] fp32 (Morton order of ``g``) -> aggregated messages [N, width] fp32.
+        """h [N, width] fp32 | bf16 (Morton order of ``g``) -> aggregated messages [N, width] in h's dtype (the sums are
+        fp32 in both cases; bf16 storage rounds them once).
 
         ``edges = (src, dst)``: an explicit dst-sorted edge list instead of ``g``'s (sharding: interior / boundary edges).
         ``cont``: the ``(out, premix)`` pair a previous call returned through ``return_state`` semantics -- the call then ADDS
         its edges' messages to ``out`` (same ``h`` rows for every dst node required) and returns ``out``."""
-        if not h.is_cuda or h.dtype != torch.float32:
-            raise RuntimeError("fused message: float32 ROCm tensor required (no CPU path)")
+        if not h.is_cuda or not self.supports(h.dtype):
+            raise RuntimeError(f"fused message: ROCm tensor in float32 (or bfloat16 for hidden >= 32) required, got "
+                               f"{h.dtype} on {h.device} (no CPU path)")
+        io, code, esz = h.dtype, _lib.dtype_code(h.dtype), h.element_size()
         N, W = h.shape
         if W != self.width or N != g.rowptr.numel() - 1:
             raise RuntimeError(f"fused message: h must be [{g.rowptr.numel() - 1}, {self.width}], got {tuple(h.shape)}")
-        if h.stride(-1) != 1 or h.stride(0) % 4 or h.data_ptr() % 16:
+        if h.stride(-1) != 1 or (h.stride(0) * esz) % 16 or h.data_ptr() % 16:
             h = h.contiguous()
         dev = h.device
         lib = _lib.load()
@@ -119,35 +130,37 @@ class FusedMessage:
             out = cont[0]
         self.last_state = None
         if N == 0:
-            return out
+            return out.to(io)
         with torch.cuda.device(dev):
-            packed = self.packed(msg1, msg2, dev)
-            if in_scale is None:
+            packed = self.packed(msg1, msg2, dev, io)
+            if in_scale is None and io == torch.float32:
                 from . import ops
                 in_scale = ops.pow2_scale([h])
+            sc = in_scale.data_ptr() if (in_scale is not None and io == torch.float32) else None
             hd = self._plans.handle(dev)
             stream = torch.cuda.current_stream(dev).cuda_stream
+            mode = "<bf16 storage, bf16 MFMA>" if io == torch.bfloat16 else "<fp16x3 split MFMA>"
             ud = int(lib.e3_msg_premix_floats_per_node(hd))
             if cont is not None:
                 premix = cont[1]
             else:
                 premix = torch.empty(N * ud, dtype=torch.float32, device=dev)
                 t0 = profiling.begin() if profiling.enabled() else None
-                _lib.check(lib.e3_msg_premix(hd, h.data_ptr(), h.stride(0), N, packed.data_ptr(), in_scale.data_ptr(),
-                                             premix.data_ptr(), stream), "e3_msg_premix")
+                _lib.check(lib.e3_msg_premix(hd, h.data_ptr(), h.stride(0), N, packed.data_ptr(), sc,
+                                             premix.data_ptr(), code, stream), "e3_msg_premix")
                 if t0 is not None:
                     # node-level GEMM h [N, (l_max+1)^2 H] x W_dst: reads h, writes the table
-                    profiling.end(f"msg_premix lmax={self.lmax} H={self.hidden} N={N}", N, 4 * N * (W + ud), t0,
-                                  flops=2 * self.hidden * ud * N, kernel="e3::msg_premix_kernel<fp16x3 split MFMA>")
+                    profiling.end(f"msg_premix lmax={self.lmax} H={self.hidden} N={N} {io}", N, N * (esz * W + 4 * ud), t0,
+                                  flops=2 * self.hidden * ud * N, kernel="e3::msg_premix_kernel" + mode)
             t0 = profiling.begin() if profiling.enabled() else None
             _lib.check(lib.e3_msg_forward(hd, h.data_ptr(), h.stride(0), N, g.pos4.data_ptr(), src.data_ptr(),
-                                          dst.data_ptr(), E, packed.data_ptr(), in_scale.data_ptr(), premix.data_ptr(),
-                                          out.data_ptr(), out.stride(0), 0 if cont is None else 1,
+                                          dst.data_ptr(), E, packed.data_ptr(), sc, premix.data_ptr(),
+                                          out.data_ptr(), out.stride(0), code, 0 if cont is None else 1,
                                           int(self.tiles_per_block), stream), "e3_msg_forward")
             if t0 is not None:
                 # algorithmic bytes: h read once, positions, the two index columns, aggregated rows written once
-                nb = 4 * N * W + 16 * N + 8 * E + 4 * N * W
-                profiling.end(f"msg_fused lmax={self.lmax} H={self.hidden} E={E}", E, nb, t0,
-                              flops=self.flops_per_edge() * E, kernel="e3::msg_fused_kernel<fp16x3 split MFMA>")
+                nb = esz * N * W + 16 * N + 8 * E + 4 * N * W
+                profiling.end(f"msg_fused lmax={self.lmax} H={self.hidden} E={E} {io}", E, nb, t0,
+                              flops=self.flops_per_edge() * E, kernel="e3::msg_fused_kernel" + mode)
         self.last_state = (out, premix)
-        return out
+        return out  # fp32 sums; callers in bf16 storage round once (SEGNNLayer)

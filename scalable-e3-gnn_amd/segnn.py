@@ -80,9 +80,10 @@ class SEGNNLayer(nn.Module):
         f32 = h.dtype == torch.float32
         r16 = self.fused and inference and self.fused_available()   # per-TP fused kernels (gather + TP + gate)
         if h.dtype == torch.bfloat16 and not r16:
-            raise RuntimeError("bf16 storage needs the fused MFMA path (inference, shapes with an MFMA instantiation)")
+            raise RuntimeError("bf16 storage needs the fused MFMA kernels (inference, hidden = 32)")
         # ---- message function -> aggregated messages a [N, width] ----
-        one_launch = self.fused and inference and f32 and self.fuse_message and self.fuse_scatter and self._msg is not None
+        one_launch = (self.fused and inference and self.fuse_message and self.fuse_scatter and self._msg is not None and
+                      self._msg.supports(h.dtype))
         if halo is not None and not (one_launch and split is not None):
             halo.exchange(h)  # blocking refresh of the ghost rows, in place
         if one_launch and halo is not None and split is not None:
@@ -90,17 +91,17 @@ class SEGNNLayer(nn.Module):
             # landed.  The operand scale comes from the owned + stale ghost rows: one binade of head room covers the
             # refreshed ghosts (they are rows of the neighbours' h of the same layer; checked in the sharding tests).
             tok = halo.start(h)
-            if h_scale is None:
+            if h_scale is None and f32:
                 h_scale = ops.pow2_scale([h], target_log2=9)
             a = self._msg.forward(h, split.graph, self.msg1, self.msg2, h_scale, edges=split.interior)
             halo.finish(h, tok)
             a = self._msg.forward(h, split.graph, self.msg1, self.msg2, h_scale, edges=split.boundary,
-                                  cont=self._msg.last_state)
+                                  cont=self._msg.last_state).to(h.dtype)
         elif one_launch:
             # one launch: SH + TP #1 + gate + TP #2 + gate + segment-sum (message.FusedMessage)
-            if h_scale is None:
+            if h_scale is None and f32:
                 h_scale = ops.pow2_scale([h])
-            a = self._msg.forward(h, g, self.msg1, self.msg2, h_scale)
+            a = self._msg.forward(h, g, self.msg1, self.msg2, h_scale).to(h.dtype)
         elif r16:
             # gather + concat + TP + gate in one kernel each: no [E, 2D+1] / raw-TP tensors in HBM
             if d.dtype != h.dtype:
@@ -157,8 +158,9 @@ class SEGNN(nn.Module):
             Y, d, A = geometry
         else:
             # per-edge Y [E, (l_max+1)^2] and d [E] are only needed off the one-launch message path
-            one_launch = (x.dtype == torch.float32 and not (torch.is_grad_enabled() and _needs_grad(self, x)) and
-                          all(l.fused and l.fuse_message and l.fuse_scatter and l._msg is not None for l in self.layers))
+            one_launch = (not (torch.is_grad_enabled() and _needs_grad(self, x)) and
+                          all(l.fused and l.fuse_message and l.fuse_scatter and l._msg is not None and
+                              l._msg.supports(x.dtype) for l in self.layers))
             Y, d, A = ops.edge_geometry(g, lmax=self.lmax, want_edge=not one_launch)
         if x.dtype == torch.bfloat16 and self.lmax != 2:
             raise RuntimeError("bf16 storage is implemented for l_max = 2 (BASELINE config 3)")

@@ -84,3 +84,45 @@ def test_bf16_segnn_forward_vs_oracle():
     want = S.forward_l2(params, H, L, "1x0e+1x1o", "1x1o", xs.float().double().numpy(), pos.numpy()[perm],
                         g.rowptr.cpu().numpy(), g.src.cpu().numpy())
     assert rel(out.float(), want) < 5e-2, rel(out.float(), want)
+
+
+@pytest.mark.parametrize("lmax,H", [(2, 32), (1, 32), (2, 64)])
+def test_bf16_fused_message_kernel_vs_oracle(lmax, H):
+    """The one-launch message function in bf16 storage (e3_msg_forward, dtype E3_BF16) against the fp64 oracle chain on
+    the same bf16-rounded features and weights: two products and two gates, messages rounded to bf16 in between."""
+    from oracle import cg
+    from scalable_e3_gnn_amd.radius_graph import radius_graph
+    from scalable_e3_gnn_amd.segnn import SEGNNLayer
+    torch.manual_seed(7 + H + lmax)
+    N = 700
+    pos = torch.rand(N, 3, generator=torch.Generator().manual_seed(8))
+    r = float((3 * 12.0 / (4 * np.pi * N)) ** (1 / 3))
+    g = radius_graph(pos.to(DEV), r, [0, 0, 0], [1, 1, 1])
+    layer = SEGNNLayer(H, lmax).bfloat16().to(DEV)
+    assert layer._msg.supports(torch.bfloat16)
+    D = H * (lmax + 1) ** 2
+    h = torch.randn(N, D, generator=torch.Generator().manual_seed(9)).bfloat16()
+    with torch.no_grad():
+        got = layer._msg.forward(h.to(DEV), g, layer.msg1, layer.msg2)
+    assert got.dtype == torch.float32 and got.shape == (N, D)
+    hid = f"{H}x0e+{H}x1o" + (f"+{H}x2e" if lmax == 2 else "")
+    gated = f"{H}x0e+{lmax * H}x0e+{H}x1o" + (f"+{H}x2e" if lmax == 2 else "")
+    blocks = [(l, H) for l in range(1, lmax + 1)]
+
+    def WN(tp):
+        W = {c: getattr(tp, "weights_" + c).detach().float().double().cpu().numpy() for c in T.CLASSES if hasattr(tp, "weights_" + c)}
+        Nn = {c: (getattr(tp, "norm_" + c).float().double().cpu().numpy() if hasattr(tp, "norm_" + c) else np.zeros(0)) for c in T.CLASSES}
+        return W, Nn
+
+    src, dst = g.src.cpu().long().numpy(), g.dst.cpu().long().numpy()
+    p64 = g.pos4[:, :3].double().cpu().numpy()
+    rel_v = p64[src] - p64[dst]
+    Y = cg.sh_component(lmax, rel_v)
+    dd = np.sqrt((rel_v * rel_v).sum(1))
+    hd = h.float().double().numpy()
+    m = np.concatenate([hd[dst], hd[src], dd[:, None]], 1)
+    m = S.gate_blocks(T.forward(f"{hid}+{hid}+1x0e", gated, lmax, m, Y, *WN(layer.msg1)), H, blocks)
+    m = S.gate_blocks(T.forward(hid, gated, lmax, m, Y, *WN(layer.msg2)), H, blocks)
+    want = np.zeros((N, D))
+    np.add.at(want, dst, m)
+    assert rel(got, want) < 2e-2, rel(got, want)
