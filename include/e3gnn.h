@@ -292,7 +292,7 @@ int e3_tp_forward_fused_scatter(const e3_tp_plan* plan, const e3_tp_segment* seg
  *   out    : [N, ld_out] fp32, columns [H | 3 H | 5 H]; zero-filled by the call unless accumulate != 0
  *   accumulate != 0: a second edge list for the SAME h rows of the dst nodes (e.g. the halo's boundary edges after the
  *            interior ones): out keeps its contents (premix is reused: it depends on dst rows only)
- *   tiles_per_block: consecutive 16-edge tiles a wave processes before it jumps (0 = a quarter of its workgroup's range)
+ *   tiles_per_block: consecutive 16-edge tiles a wave processes before it jumps to its workgroup's next chunk (0 = 4)
  * One plan belongs to the device current at its first use.
  * ================================================================================================= */
 typedef struct e3_msg_plan e3_msg_plan;

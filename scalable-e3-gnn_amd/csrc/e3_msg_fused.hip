@@ -623,7 +623,7 @@ template <int LMAX, int TT, bool IO16>
 __global__ __launch_bounds__(256, msg_waves_per_simd(LMAX, TT)) void msg_fused_kernel(
     const void* __restrict__ hv, int64_t ldh, const float4* __restrict__ pos4, const int32_t* __restrict__ src,
     const int32_t* __restrict__ dst, int64_t E, const float* __restrict__ packed, const float* __restrict__ U,
-    const float* __restrict__ in_scale, float* __restrict__ out, int64_t ldo, int64_t tiles_per_wg, int blk) {
+    const float* __restrict__ in_scale, float* __restrict__ out, int64_t ldo, int blk) {
   using G = MsgGeom<LMAX, TT>;
   constexpr int H = G::H, D = G::D, T0 = G::T(0), NS = G::NS;
   extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -651,15 +651,18 @@ __global__ __launch_bounds__(256, msg_waves_per_simd(LMAX, TT)) void msg_fused_k
   const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(packed + G::o_w), 0, 3 * G::nblk() * 2048, 0x00020000);
 
-  // workgroup -> contiguous tile range, XCD-aware: workgroups b, b + 8, b + 16, ... share an XCD (round-robin dispatch),
-  // so the XCD with label b & 7 gets one contiguous eighth of the tiles and its L2 sees one spatial range of h / U
+  // tile -> wave map, XCD-aware.  Workgroups b, b + 8, b + 16, ... share an XCD (round-robin dispatch; `b & 7` is a label
+  // of the group, not the XCD's id): the group gets one contiguous eighth of the (Morton-ordered) tiles, and INSIDE the
+  // eighth its workgroups are dealt chunks of 4 blk tiles round-robin -- so the ~256 waves that share one 4 MiB L2 sweep
+  // through the same spatial neighbourhood together and the gathered h[src] / pre-mix rows are fetched once per XCD
+  // instead of once per edge.  A wave owns `blk` consecutive tiles of a chunk (its segment sum carries across them).
   const int64_t ntiles = (E + 15) / 16;
-  const int nwg = gridDim.x;
-  const int per_xcd = nwg >> 3;  // grid is a multiple of 8
-  const int64_t pos = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-  const int64_t wg_lo = pos * tiles_per_wg;
-  int64_t wg_hi = wg_lo + tiles_per_wg;
-  if (wg_hi > ntiles) wg_hi = ntiles;
+  const int per_xcd = (int)(gridDim.x >> 3);  // grid is a multiple of 8
+  const int64_t tiles_per_xcd = (ntiles + 7) / 8;
+  const int64_t xcd_lo = (int64_t)(blockIdx.x & 7) * tiles_per_xcd;
+  int64_t xcd_hi = xcd_lo + tiles_per_xcd;
+  if (xcd_hi > ntiles) xcd_hi = ntiles;
+  const int64_t wg_idx = blockIdx.x >> 3;
 
   // running segment sum across consecutive tiles of this wave: node id (wave uniform) + NQ output columns per lane
   // (the gated message row [H | 3 H | 5 H] is exactly an `out` row: column 64 q + lane)
@@ -688,12 +691,13 @@ __global__ __launch_bounds__(256, msg_waves_per_simd(LMAX, TT)) void msg_fused_k
     s_ = src[e];
     d_ = dst[e];
   };
-  // outer = blocks of `blk` consecutive tiles dealt round-robin to the four waves, inner = the tiles of a block.
+  // outer = this workgroup's chunks, inner = the tiles of this wave's block of the chunk.
   // (A workgroup barrier per tile, so that the waves share one weight stream through L1, measured 26.9 vs 26.5 ms.)
-  const int64_t n_outer = (tiles_per_wg + 4 * (int64_t)blk - 1) / (4 * (int64_t)blk);
+  const int64_t chunk = 4 * (int64_t)blk;
+  const int64_t n_outer = (tiles_per_xcd + chunk * per_xcd - 1) / (chunk * per_xcd);
   for (int64_t ob = 0; ob < n_outer; ++ob) {
-    const int64_t b0 = wg_lo + (ob * 4 + wave) * blk;
-    const int64_t b1 = b0 + blk < wg_hi ? b0 + blk : wg_hi;
+    const int64_t b0 = xcd_lo + (ob * per_xcd + wg_idx) * chunk + (int64_t)wave * blk;
+    const int64_t b1 = b0 + blk < xcd_hi ? b0 + blk : xcd_hi;
     int sid_n = 0, did_n = 0;
     if (b0 < b1) load_ids(b0, sid_n, did_n);
     for (int64_t ti = 0; ti < blk; ++ti) {
@@ -1183,12 +1187,10 @@ int e3_msg_forward(e3_msg_plan* P, const void* h, int64_t ld_h, int64_t N, const
   int nwg = 256 * k.waves_per_simd;  // 4 waves per workgroup; waves_per_simd workgroups per CU
   nwg = (int)std::min<int64_t>(nwg, (ntiles + 3) / 4);
   nwg = std::max(8, (nwg + 7) / 8 * 8);
-  const int64_t tiles_per_wg = (ntiles + nwg - 1) / nwg;
-  int blk = tiles_per_block > 0 ? tiles_per_block : (int)std::min<int64_t>((tiles_per_wg + 3) / 4, 1 << 20);
-  if (blk < 1) blk = 1;
+  int blk = tiles_per_block > 0 ? tiles_per_block : 4;  // default: 64 edges (2-3 dst nodes) per wave block
+  if (blk > (1 << 20)) blk = 1 << 20;
   const size_t lds = (size_t)(k.lds_tab + 4 * k.lds_wave) * 4;
-  void* args[] = {&h, &ld_h, &pos4, &src, &dst, &E, &packed, &premix, &in_scale, &out, &ld_out,
-                  const_cast<int64_t*>(&tiles_per_wg), &blk};
+  void* args[] = {&h, &ld_h, &pos4, &src, &dst, &E, &packed, &premix, &in_scale, &out, &ld_out, &blk};
   if (hipLaunchKernel(k.fused[io], dim3(nwg), dim3(256), args, lds, s) != hipSuccess) return E3_ERR_HIP;
   return E3_OK;
 }
