@@ -40,7 +40,14 @@
 #define E3_MSG_WPS 2   // waves per SIMD the H = 32, l_max = 2 kernel is compiled for (1: 48-55 ms at any prefetch distance)
 #endif
 
+#ifndef E3_MSG_STAMP
+#define E3_MSG_STAMP 0  // 1: per-phase cycle counters (s_memtime) summed into g_msg_stamps -- development builds only
+#endif                  //    (tools/build_variant.sh stamp -DE3_MSG_STAMP=1; STAMPS=1 tools/msg_micro.py prints them)
+
 namespace e3 {
+#if E3_MSG_STAMP
+__device__ unsigned long long g_msg_stamps[8];
+#endif
 
 #include "e3_tp_mfma_core.h"
 
@@ -668,6 +675,12 @@ __global__ __launch_bounds__(256, msg_waves_per_simd(LMAX, TT)) void msg_fused_k
   // (the gated message row [H | 3 H | 5 H] is exactly an `out` row: column 64 q + lane)
   constexpr int NQ = (D + 63) / 64;
   constexpr int RS = D + 1;  // LDS row stride of the transposed tile (floats, odd)
+#if E3_MSG_STAMP
+  uint32_t st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = (uint32_t)__builtin_readcyclecounter();
+#define E3_STAMP(i) { const uint32_t t_ = (uint32_t)__builtin_readcyclecounter(); st_acc[i] += t_ - st_t; st_t = t_; }
+#else
+#define E3_STAMP(i)
+#endif
   int cur = -1;
   float carry[NQ];
 #pragma unroll
@@ -722,6 +735,7 @@ __global__ __launch_bounds__(256, msg_waves_per_simd(LMAX, TT)) void msg_fused_k
       // (the previous tile's LDS reads must have returned before the copies may land)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       wave_sync_lds();
+      E3_STAMP(5)  // loop top: ids, reloads
       {
         auto stage_region = [&](auto utag, auto otag, char* dstb) {
           constexpr int UNITS = decltype(utag)::value, SRCOFF = decltype(otag)::value;  // units per row, first source element
@@ -776,8 +790,10 @@ __global__ __launch_bounds__(256, msg_waves_per_simd(LMAX, TT)) void msg_fused_k
 #pragma unroll
         for (int c = 0; c < 5; ++c) a2[t][c] = zero4;
 
+      E3_STAMP(0)  // gather issue + geometry
       wait_vm0();
       wave_sync_lds();
+      E3_STAMP(1)  // gather wait
 
       // ---- tensor product #1: x from the staged rows, dst half as accumulator initial values ----
       {
@@ -803,6 +819,7 @@ __global__ __launch_bounds__(256, msg_waves_per_simd(LMAX, TT)) void msg_fused_k
         tp_core<LMAX, TT, true, IO16>(cx, y, xload, a0, a1, a2);
       }
 
+      E3_STAMP(2)  // product #1
       // ---- gate #1; the messages stay in accumulator layout = the B-operand layout of product #2 ----
       // (norm1 already carries 1 / (sw1 xs)); row scale for the fp16 split: max |m| of the lane's edge -> 2^10
       float amax = 0.f;
@@ -878,6 +895,7 @@ __global__ __launch_bounds__(256, msg_waves_per_simd(LMAX, TT)) void msg_fused_k
       }
       wave_sync_lds();
 
+      E3_STAMP(3)  // gate #1 + park
       // ---- tensor product #2 ----
 #pragma unroll
       for (int t = 0; t < T0; ++t) a0[t] = zero4;
@@ -911,6 +929,7 @@ __global__ __launch_bounds__(256, msg_waves_per_simd(LMAX, TT)) void msg_fused_k
         tp_core<LMAX, TT, false, IO16>(cx, y, xload, a0, a1, a2);
       }
 
+      E3_STAMP(4)  // product #2
       // ---- gate #2, then the segment sum: the whole gated tile goes to LDS as [row][output column] (the accumulators are
       //      dead from here on), lane = output column walks the 16 rows and adds runs of equal dst; the last run is carried
       //      into the wave's next tile ----
@@ -946,6 +965,7 @@ __global__ __launch_bounds__(256, msg_waves_per_simd(LMAX, TT)) void msg_fused_k
         put_block(std::integral_constant<int, 3>{}, a1, G::slot0(1), TT, wbuf + j * RS + H + 12 * g);
         if constexpr (LMAX == 2) put_block(std::integral_constant<int, 5>{}, a2, G::slot0(2), 2 * TT, wbuf + j * RS + 4 * H + 20 * g);
         wave_sync_lds();
+        E3_STAMP(6)  // gate #2 + transposed writes
         const float* sp = wbuf + lane;
 #pragma unroll
         for (int rb = 0; rb < 16; rb += 4) {
@@ -968,10 +988,16 @@ __global__ __launch_bounds__(256, msg_waves_per_simd(LMAX, TT)) void msg_fused_k
           }
         }
       }
+      E3_STAMP(7)  // run sums + flushes
     }
     flush();  // the wave's next tile is not the successor of this one
     cur = -1;
   }
+#if E3_MSG_STAMP
+  if (lane == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd(&g_msg_stamps[i], (unsigned long long)st_acc[i]);
+#endif
+#undef E3_STAMP
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1195,4 +1221,14 @@ int e3_msg_forward(e3_msg_plan* P, const void* h, int64_t ld_h, int64_t N, const
   return E3_OK;
 }
 
+#if E3_MSG_STAMP
+int e3_msg_debug_stamps(unsigned long long* out8, int reset) {
+  if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(e3::g_msg_stamps), 64) != hipSuccess) return E3_ERR_HIP;
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(e3::g_msg_stamps), z, 64) != hipSuccess) return E3_ERR_HIP;
+  }
+  return E3_OK;
+}
+#endif
 }  // extern "C"

@@ -1,3 +1,1 @@
-timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/abl_tests.log 2>&1; echo "rc=$?" >> gpurun_out/abl_tests.log
-for i in 1 2; do timeout -k 10 120 python tools/msg_micro.py 2>&1 | grep "ms/launch" >> gpurun_out/abl.txt; done
-python bench.py --no-cpu-baseline > gpurun_out/abl_bench.log 2>&1
+E3_EXP_LIB=l32s STAMPS=1 timeout -k 10 200 python tools/msg_micro.py >> gpurun_out/stamps.txt 2>&1

@@ -40,6 +40,18 @@ for tpb in [int(v) for v in os.environ.get("TPB", "0").split(",")]:
             layer._msg.forward(h, g, layer.msg1, layer.msg2, sc, edges=edges)
         e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
+    if os.environ.get("STAMPS"):  # per-phase cycle counters of a -DE3_MSG_STAMP=1 build (development)
+        import ctypes
+        lib = ctypes.CDLL(_L.LIB_PATH)
+        buf = (ctypes.c_ulonglong * 8)()
+        lib.e3_msg_debug_stamps(buf, 1)
+        layer._msg.forward(h, g, layer.msg1, layer.msg2, sc, edges=edges); torch.cuda.synchronize()
+        lib.e3_msg_debug_stamps(buf, 0)
+        names = ["gather issue + geometry", "gather wait", "product #1", "gate #1 + park", "product #2", "loop top (ids, reloads)",
+                 "gate #2 + transposed writes", "run sums + flushes"]
+        tot = sum(buf[:8])
+        for nme, v in zip(names, buf[:8]):
+            print(f"   stamp {nme:32s} {v/tot*100:5.1f} %   {v/((E+15)//16):9.0f} cycles per tile and wave")
     fl = layer._msg.flops_per_edge() * E
     print(f"[{os.environ.get('E3_EXP_LIB','default')}] N={N} E={E} lmax={lmax} H={H} tpb={tpb} zero_idx={bool(edges)}: {ms:.2f} ms/launch pair  {E/ms/1e3:.0f} Medges/s  "
           f"{fl/ms/1e9:.1f} TFLOP/s algorithmic ({3*fl/ms/1e9/2500*100:.1f} % of bf16/f16 MFMA peak executed x3)")
