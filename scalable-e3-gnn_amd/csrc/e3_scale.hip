@@ -20,18 +20,34 @@ struct ScaleArgs {
 };
 
 // out4: [0] s, [1] 1/s, [2] float bits of the running max |x| (zeroed on the stream before this kernel), [3] unused
+// A segment whose rows are whole float4s (cols and ld multiples of 4, 16-byte aligned base) is read 16 bytes per lane:
+// dense segments as one flat range, strided ones row by row (a workgroup per row step, no per-element division).
 __global__ __launch_bounds__(256) void absmax_kernel(ScaleArgs a, uint32_t* bits) {
   float m = 0.f;
   for (int t = 0; t < a.n; ++t) {
-    const int64_t total = a.rows[t] * a.cols[t];
-    const bool dense = a.ld[t] == a.cols[t];
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-      int64_t off = i;
-      if (!dense) {
-        const int64_t r = i / a.cols[t];
-        off = r * a.ld[t] + (i - r * a.cols[t]);
+    const int64_t rows = a.rows[t], ld = a.ld[t];
+    const int cols = a.cols[t];
+    const float* base = a.base[t];
+    const bool vec = ((cols | ld) & 3) == 0 && (reinterpret_cast<uintptr_t>(base) & 15) == 0;
+    if (vec && ld == cols) {
+      const float4* b4 = reinterpret_cast<const float4*>(base);
+      const int64_t n4 = rows * cols / 4;
+      for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 v = b4[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
       }
-      m = fmaxf(m, fabsf(a.base[t][off]));
+    } else if (vec) {
+      const int c4 = cols / 4;
+      for (int64_t r = blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (int64_t)gridDim.x * 4) {  // a wave per row
+        const float4* b4 = reinterpret_cast<const float4*>(base + r * ld);
+        for (int c = threadIdx.x & 63; c < c4; c += 64) {
+          const float4 v = b4[c];
+          m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        }
+      }
+    } else {
+      for (int64_t r = blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (int64_t)gridDim.x * 4)
+        for (int c = threadIdx.x & 63; c < cols; c += 64) m = fmaxf(m, fabsf(base[r * ld + c]));
     }
   }
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
@@ -85,7 +101,7 @@ int e3_pow2_scale(const e3_tp_segment* segs, const int64_t* nrows, int nseg, int
   hipStream_t s = (hipStream_t)stream;
   E3_HIP_CHECK(hipMemsetAsync(out4, 0, 16, s));
   if (total > 0) {
-    const int grid = (int)std::min<int64_t>((total + 255) / 256, 2048);
+    const int grid = (int)std::min<int64_t>((total + 1023) / 1024, 2048);
     hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, s, a, reinterpret_cast<uint32_t*>(out4) + 2);
   }
   hipLaunchKernelGGL(scale_finalize_kernel, dim3(1), dim3(1), 0, s, out4, target_log2);

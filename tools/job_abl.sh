@@ -1,1 +1,2 @@
-E3_EXP_LIB=l32s STAMPS=1 timeout -k 10 200 python tools/msg_micro.py >> gpurun_out/stamps.txt 2>&1
+timeout -k 10 300 python -m pytest tests/test_scale_gpu.py tests/test_parity_bench_mode_gpu.py -x -q > gpurun_out/abl_tests.log 2>&1; echo "rc=$?" >> gpurun_out/abl_tests.log
+python bench.py --no-cpu-baseline --no-bf16-leg --timing-json gpurun_out/abl_timing.json > gpurun_out/abl_bench.log 2>&1
