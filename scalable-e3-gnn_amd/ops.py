@@ -278,6 +278,13 @@ def pow2_scale(tensors, target_log2: int = 10) -> torch.Tensor:
     return out
 
 
+def join_pow2_scales(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """The operand scale of the union of two tensor sets from their scales (same target): the smaller ``s``, the larger
+    ``1/s`` -- lets a caller that already knows the scale of one operand (``h``: returned by ``add_pow2_scale``) scan
+    only the other one.  Device side, no host sync."""
+    return torch.stack([torch.minimum(a[0], b[0]), torch.maximum(a[1], b[1]), torch.maximum(a[2], b[2]), a[3]])
+
+
 def add_pow2_scale(h: torch.Tensor, u: torch.Tensor, target_log2: int = 10):
     """``h + u`` and the operand scale of the sum in one pass (``e3_add_pow2_scale``) -> (sum, scale)."""
     _check(h, "h")

@@ -121,7 +121,11 @@ class SEGNNLayer(nn.Module):
             a = ops.segment_sum(m, g)
         # ---- node update ----
         if r16:
-            u = self.upd1.forward_fused([(h, None), (a, None)], A, gate=True)
+            # operand scale of [h | a]: h's is known (the previous layer returned it), so only `a` is scanned
+            sc = None
+            if f32 and h_scale is not None and halo is None:
+                sc = ops.join_pow2_scales(h_scale, ops.pow2_scale([a]))
+            u = self.upd1.forward_fused([(h, None), (a, None)], A, gate=True, in_scale=sc)
         else:
             u = self._gate(self.upd1(torch.cat([h, a], 1), A))
         u = self.upd2(u, A)
