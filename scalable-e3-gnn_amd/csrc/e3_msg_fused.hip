@@ -101,8 +101,8 @@ struct MsgGeom {
   static constexpr int blk_floats = 64 * 8;  // 64 lanes x (hi uint4 + lo uint4)
   static constexpr int64_t total_floats = (int64_t)o_w + 3LL * nblk() * blk_floats;
   static constexpr int lds_tab = 2 * NS * 16 + WD;  // floats of tables kept in LDS per workgroup
-  static constexpr int lds_wave = 16 * D + 16;      // floats per wave: staged h[src] rows, later the parked messages, then the
-                                                    // transposed tile with row stride D + 1
+  static constexpr int lds_wave = 16 * (D + 4);     // floats per wave: staged h[src] rows, later the parked messages, then the
+                                                    // transposed tile with row stride D + 4
 };
 
 // k slot jj (0..7) of k group g inside a 32-channel K step  <->  channel: the accumulator layout of the previous product
@@ -674,7 +674,11 @@ __global__ __launch_bounds__(256, msg_waves_per_simd(LMAX, TT)) void msg_fused_k
   // running segment sum across consecutive tiles of this wave: node id (wave uniform) + NQ output columns per lane
   // (the gated message row [H | 3 H | 5 H] is exactly an `out` row: column 64 q + lane)
   constexpr int NQ = (D + 63) / 64;
-  constexpr int RS = D + 1;  // LDS row stride of the transposed tile (floats, odd)
+  // LDS row stride of the transposed tile (floats): rows stay 16-byte aligned, so a lane stores its 4 channels x (2l+1)
+  // components of a degree -- contiguous in the output row -- as 2l+1 ds_write_b128 (18 per tile instead of 288 b32 stores
+  // with 2-4 way bank conflicts); D + 4 = 73 16-byte units per row for H = 32: the 16 rows of a lane group fall on 16 different bank
+  // quads.  The column reads of the run sums are consecutive lanes -> consecutive words for any stride.
+  constexpr int RS = D + 4;
 #if E3_MSG_STAMP
   uint32_t st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = (uint32_t)__builtin_readcyclecounter();
 #define E3_STAMP(i) { const uint32_t t_ = (uint32_t)__builtin_readcyclecounter(); st_acc[i] += t_ - st_t; st_t = t_; }
@@ -940,11 +944,13 @@ __global__ __launch_bounds__(256, msg_waves_per_simd(LMAX, TT)) void msg_fused_k
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
           const f32x4 nv = nt2[4 * t];
+          f32x4 o;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float sv = a0[t][r] * nv[r] * isrow;
-            wp[16 * t + r] = sv * sigmoid_(sv);
+            o[r] = sv * sigmoid_(sv);
           }
+          *reinterpret_cast<f32x4*>(wp + 16 * t) = o;
         }
         auto put_block = [&](auto dtag, auto& acc, const int slot, const int gslot, float* wq) {
           constexpr int Dc = decltype(dtag)::value;
@@ -954,12 +960,16 @@ __global__ __launch_bounds__(256, msg_waves_per_simd(LMAX, TT)) void msg_fused_k
             float gt[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) gt[r] = sigmoid_(a0[gslot + t][r] * gn[r] * isrow) * isrow;
+            float o[4 * Dc];  // the lane's 4 channels x Dc components: one contiguous piece of the output row
 #pragma unroll
             for (int c = 0; c < Dc; ++c) {
               const f32x4 nv = nt2[4 * (slot + Dc * t + c)];
 #pragma unroll
-              for (int r = 0; r < 4; ++r) wq[(16 * t + r) * Dc + c] = acc[t][c][r] * nv[r] * gt[r];
+              for (int r = 0; r < 4; ++r) o[r * Dc + c] = acc[t][c][r] * nv[r] * gt[r];
             }
+            f32x4* dq = reinterpret_cast<f32x4*>(wq + 16 * t * Dc);
+#pragma unroll
+            for (int k = 0; k < Dc; ++k) dq[k] = f32x4{o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]};
           }
         };
         put_block(std::integral_constant<int, 3>{}, a1, G::slot0(1), TT, wbuf + j * RS + H + 12 * g);
