@@ -663,13 +663,15 @@ __global__ __launch_bounds__(256, msg_waves_per_simd(LMAX, TT)) void msg_fused_k
   // eighth its workgroups are dealt chunks of 4 blk tiles round-robin -- so the ~256 waves that share one 4 MiB L2 sweep
   // through the same spatial neighbourhood together and the gathered h[src] / pre-mix rows are fetched once per XCD
   // instead of once per edge.  A wave owns `blk` consecutive tiles of a chunk (its segment sum carries across them).
-  const int64_t ntiles = (E + 15) / 16;
+  // (all of it in 32-bit scalars -- E < 2^31 because the edge ids are int32: 64-bit products are VALU instructions, which
+  // turn the tile loop's control flow into vector code with its counters spilled to scratch)
+  const int ntiles = (int)((E + 15) / 16);
   const int per_xcd = (int)(gridDim.x >> 3);  // grid is a multiple of 8
-  const int64_t tiles_per_xcd = (ntiles + 7) / 8;
-  const int64_t xcd_lo = (int64_t)(blockIdx.x & 7) * tiles_per_xcd;
-  int64_t xcd_hi = xcd_lo + tiles_per_xcd;
-  if (xcd_hi > ntiles) xcd_hi = ntiles;
-  const int64_t wg_idx = blockIdx.x >> 3;
+  const int tiles_per_xcd = (ntiles + 7) / 8;
+  const int xcd_lo = (int)(blockIdx.x & 7) * tiles_per_xcd;
+  const int xcd_hi = xcd_lo + tiles_per_xcd < ntiles ? xcd_lo + tiles_per_xcd : ntiles;
+  const int wg_idx = (int)(blockIdx.x >> 3);
+  const int Ei = (int)E;
 
   // running segment sum across consecutive tiles of this wave: node id (wave uniform) + NQ output columns per lane
   // (the gated message row [H | 3 H | 5 H] is exactly an `out` row: column 64 q + lane)
@@ -689,39 +691,43 @@ __global__ __launch_bounds__(256, msg_waves_per_simd(LMAX, TT)) void msg_fused_k
   float carry[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; ++q) carry[q] = 0.f;
+  // (vmcnt is in-order: a wait for ANY vector-memory operation issued after a flush also waits for the acknowledgement of
+  // its atomics, a round trip to the memory side.  The flush must therefore not reload anything from scratch -- the lane
+  // id is regenerated (v_mbcnt) instead of kept, and the row address is scalar base + lane offset, so that the compiler
+  // has no `out + lane` pointer pair to hoist out of the tile loop and spill.)
   auto flush = [&]() {
     if (cur >= 0) {
-      float* o = out + (int64_t)cur * ldo + lane;
+      int ln;
+      asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+      float* o = out + (int64_t)cur * ldo;  // wave uniform
 #pragma unroll
       for (int q = 0; q < NQ; ++q)
-        if (64 * q + lane < D) __builtin_amdgcn_global_atomic_fadd_f32(o + 64 * q, carry[q]);
+        if (64 * q + ln < D) __builtin_amdgcn_global_atomic_fadd_f32(o + (64 * q + ln), carry[q]);
     }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) carry[q] = 0.f;
   };
 
   // edge ids are fetched one tile ahead (the tile's first instructions need them for the gather addresses)
-  auto load_ids = [&](int64_t tile, int& s_, int& d_) {
-    const int64_t row0 = tile * 16;
-    const int nrows = (int)((E - row0) < 16 ? (E - row0) : 16);
-    const int64_t e = row0 + (j < nrows ? j : nrows - 1);
+  auto load_ids = [&](int tile, int& s_, int& d_) {
+    const int row0 = tile * 16;
+    const int nrows = Ei - row0 < 16 ? Ei - row0 : 16;
+    const int e = row0 + (j < nrows ? j : nrows - 1);
     s_ = src[e];
     d_ = dst[e];
   };
   // outer = this workgroup's chunks, inner = the tiles of this wave's block of the chunk.
   // (A workgroup barrier per tile, so that the waves share one weight stream through L1, measured 26.9 vs 26.5 ms.)
-  const int64_t chunk = 4 * (int64_t)blk;
-  const int64_t n_outer = (tiles_per_xcd + chunk * per_xcd - 1) / (chunk * per_xcd);
-  for (int64_t ob = 0; ob < n_outer; ++ob) {
-    const int64_t b0 = xcd_lo + (ob * per_xcd + wg_idx) * chunk + (int64_t)wave * blk;
-    const int64_t b1 = b0 + blk < xcd_hi ? b0 + blk : xcd_hi;
+  const int chunk = 4 * blk;
+  const int n_outer = (tiles_per_xcd + chunk * per_xcd - 1) / (chunk * per_xcd);
+  for (int ob = 0; ob < n_outer; ++ob) {
+    const int b0 = __builtin_amdgcn_readfirstlane(xcd_lo + (ob * per_xcd + wg_idx) * chunk + wave * blk);
+    const int b1 = __builtin_amdgcn_readfirstlane(b0 + blk < xcd_hi ? b0 + blk : xcd_hi);
     int sid_n = 0, did_n = 0;
     if (b0 < b1) load_ids(b0, sid_n, did_n);
-    for (int64_t ti = 0; ti < blk; ++ti) {
-      const int64_t tile = b0 + ti;
-      if (tile >= b1) break;
-      const int64_t row0 = tile * 16;
-      const int nrows = (int)((E - row0) < 16 ? (E - row0) : 16);
+    for (int tile = b0; tile < b1; ++tile) {
+      const int row0 = tile * 16;
+      const int nrows = Ei - row0 < 16 ? Ei - row0 : 16;
       const int sid = sid_n, did = did_n;
       if (tile + 1 < b1) load_ids(tile + 1, sid_n, did_n);
       // per-tile opaque copies of loop-invariant addresses: without them LICM hoists ~50 table reads (200 registers) and
@@ -976,14 +982,18 @@ __global__ __launch_bounds__(256, msg_waves_per_simd(LMAX, TT)) void msg_fused_k
         if constexpr (LMAX == 2) put_block(std::integral_constant<int, 5>{}, a2, G::slot0(2), 2 * TT, wbuf + j * RS + 4 * H + 20 * g);
         wave_sync_lds();
         E3_STAMP(6)  // gate #2 + transposed writes
-        const float* sp = wbuf + lane;
+        // from here to the next tile's gather nothing may wait on vmcnt behind a flush (see `flush`): the lane id is
+        // regenerated, the next tile's ids are made to have arrived
+        int ln;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+        const float* sp = wbuf + ln;
 #pragma unroll
         for (int rb = 0; rb < 16; rb += 4) {
           float v[4][NQ];
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) v[rr][q] = (64 * q + lane < D) ? sp[(rb + rr) * RS + 64 * q] : 0.f;
+            for (int q = 0; q < NQ; ++q) v[rr][q] = (64 * q + ln < D) ? sp[(rb + rr) * RS + 64 * q] : 0.f;
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr) {
             const int dn = __builtin_amdgcn_readlane(sd, rb + rr);
@@ -1205,7 +1215,7 @@ int e3_msg_premix(e3_msg_plan* P, const void* h, int64_t ld_h, int64_t N, const 
 int e3_msg_forward(e3_msg_plan* P, const void* h, int64_t ld_h, int64_t N, const float* pos4, const int32_t* src,
                    const int32_t* dst, int64_t E, const void* packed, const float* in_scale, const float* premix,
                    float* out, int64_t ld_out, int dtype, int accumulate, int tiles_per_block, void* stream) {
-  if (!P || N < 0 || E < 0) return E3_ERR_INVALID_ARG;
+  if (!P || N < 0 || E < 0 || E > 0x7fffffffLL - 16) return E3_ERR_INVALID_ARG;  // edge ids are int32
   if (!e3_msg_supports(P, dtype)) return E3_ERR_UNSUPPORTED;
   const MsgKernels& k = *P->k;
   const int io = dtype == E3_BF16 ? 1 : 0, es = io ? 2 : 4;
@@ -1224,7 +1234,7 @@ int e3_msg_forward(e3_msg_plan* P, const void* h, int64_t ld_h, int64_t N, const
   nwg = (int)std::min<int64_t>(nwg, (ntiles + 3) / 4);
   nwg = std::max(8, (nwg + 7) / 8 * 8);
   int blk = tiles_per_block > 0 ? tiles_per_block : 4;  // default: 64 edges (2-3 dst nodes) per wave block
-  if (blk > (1 << 20)) blk = 1 << 20;
+  if (blk > (1 << 16)) blk = 1 << 16;
   const size_t lds = (size_t)(k.lds_tab + 4 * k.lds_wave) * 4;
   void* args[] = {&h, &ld_h, &pos4, &src, &dst, &E, &packed, &premix, &in_scale, &out, &ld_out, &blk};
   if (hipLaunchKernel(k.fused[io], dim3(nwg), dim3(256), args, lds, s) != hipSuccess) return E3_ERR_HIP;
