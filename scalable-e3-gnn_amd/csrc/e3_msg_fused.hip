@@ -644,6 +644,7 @@ __global__ __launch_bounds__(256, msg_waves_per_simd(LMAX, TT)) void msg_fused_k
   float* n2tab = n1tab + NS * 16;
   float* wdtab = n2tab + NS * 16;
   float* wbuf = wdtab + G::WD + (size_t)wave * G::lds_wave;
+  int* idbuf = reinterpret_cast<int*>(wdtab + G::WD + (size_t)4 * G::lds_wave) + wave * 64;  // edge ids of the wave's next tile
   // bf16 storage needs no operand scales (bf16 has the fp32 exponent range): xs = 1, messages unscaled
   constexpr int ES = IO16 ? 2 : 4;  // bytes per stored feature element
   const char* h = reinterpret_cast<const char*>(hv);
@@ -708,13 +709,17 @@ __global__ __launch_bounds__(256, msg_waves_per_simd(LMAX, TT)) void msg_fused_k
     for (int q = 0; q < NQ; ++q) carry[q] = 0.f;
   };
 
-  // edge ids are fetched one tile ahead (the tile's first instructions need them for the gather addresses)
-  auto load_ids = [&](int tile, int& s_, int& d_) {
+  // The edge ids of a tile (16 src, 16 dst) are copied into LDS one tile ahead by a 4-byte LDS-DMA issued together with the
+  // previous tile's gather copies (lanes 0-15: src, 16-31: dst; the upper half repeats them): they land under the wait the
+  // gather needs anyway and occupy no register across the products.  (As prefetched VGPRs they were spilled right after
+  // the load -- `global_load; s_waitcnt vmcnt(0); scratch_store`, twice per tile -- and reloaded behind the atomics.)
+  auto copy_ids = [&](int tile, int ln) {
     const int row0 = tile * 16;
     const int nrows = Ei - row0 < 16 ? Ei - row0 : 16;
-    const int e = row0 + (j < nrows ? j : nrows - 1);
-    s_ = src[e];
-    d_ = dst[e];
+    const int jl = ln & 15;
+    const int e = row0 + (jl < nrows ? jl : nrows - 1);
+    const int32_t* p = ((ln & 16) ? dst : src) + e;
+    __builtin_amdgcn_global_load_lds((glb_void_t*)p, (lds_void_t*)idbuf, 4, 0, 0);
   };
   // outer = this workgroup's chunks, inner = the tiles of this wave's block of the chunk.
   // (A workgroup barrier per tile, so that the waves share one weight stream through L1, measured 26.9 vs 26.5 ms.)
@@ -723,13 +728,19 @@ __global__ __launch_bounds__(256, msg_waves_per_simd(LMAX, TT)) void msg_fused_k
   for (int ob = 0; ob < n_outer; ++ob) {
     const int b0 = __builtin_amdgcn_readfirstlane(xcd_lo + (ob * per_xcd + wg_idx) * chunk + wave * blk);
     const int b1 = __builtin_amdgcn_readfirstlane(b0 + blk < xcd_hi ? b0 + blk : xcd_hi);
-    int sid_n = 0, did_n = 0;
-    if (b0 < b1) load_ids(b0, sid_n, did_n);
+    if (b0 < b1) {  // the block's first tile: its ids are copied now
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      wave_sync_lds();
+      copy_ids(b0, lane);
+      wait_vm0();
+      wave_sync_lds();
+    }
     for (int tile = b0; tile < b1; ++tile) {
       const int row0 = tile * 16;
       const int nrows = Ei - row0 < 16 ? Ei - row0 : 16;
-      const int sid = sid_n, did = did_n;
-      if (tile + 1 < b1) load_ids(tile + 1, sid_n, did_n);
+      int lt;  // lane id, regenerated per tile (the kernel-level copy is spilled across the products)
+      asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lt));
+      const int sid = idbuf[lt & 15], did = idbuf[16 + (lt & 15)];
       // per-tile opaque copies of loop-invariant addresses: without them LICM hoists ~50 table reads (200 registers) and
       // the block addresses out of the tile loop and spills them
       uint32_t woff = lane * 16;
@@ -747,6 +758,8 @@ __global__ __launch_bounds__(256, msg_waves_per_simd(LMAX, TT)) void msg_fused_k
       wave_sync_lds();
       E3_STAMP(5)  // loop top: ids, reloads
       {
+        int ls;  // lane id, regenerated: the kernel-level copy is spilled across the products
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ls));
         auto stage_region = [&](auto utag, auto otag, char* dstb) {
           constexpr int UNITS = decltype(utag)::value, SRCOFF = decltype(otag)::value;  // units per row, first source element
           if constexpr (UNITS >= 64) {
@@ -756,13 +769,13 @@ __global__ __launch_bounds__(256, msg_waves_per_simd(LMAX, TT)) void msg_fused_k
               const char* rowp = h + ((int64_t)rid * ldh + SRCOFF) * ES;
 #pragma unroll
               for (int k = 0; k < UNITS / 64; ++k)
-                __builtin_amdgcn_global_load_lds((glb_void_t*)(rowp + (k * 64 + lane) * 16),
+                __builtin_amdgcn_global_load_lds((glb_void_t*)(rowp + (k * 64 + ls) * 16),
                                                  (lds_void_t*)(dstb + (r * UNITS + k * 64) * 16), 16, 0, 0);
             }
           } else {
             constexpr int RPI = 64 / UNITS;  // rows per instruction
             static_assert(RPI <= 16, "region rows shorter than 4 units are not supported");
-            const int u = lane & (UNITS - 1), rl = lane / UNITS;
+            const int u = ls & (UNITS - 1), rl = ls / UNITS;
             int rid[16 / RPI];  // all shuffles first: they are LDS-pipe instructions, and hipcc guards every LDS access
 #pragma unroll                  // behind an LDS-DMA in flight with vmcnt(0), which would serialise the copies
             for (int it = 0; it < 16 / RPI; ++it) rid[it] = __shfl(sid, it * RPI + rl);
@@ -774,6 +787,7 @@ __global__ __launch_bounds__(256, msg_waves_per_simd(LMAX, TT)) void msg_fused_k
         };
         // element counts per row: l_max 2: A = [1o | 2e] = 8 H, B = [0e] = H; l_max 1: 4 H
         char* wb = reinterpret_cast<char*>(wbuf);
+        if (tile + 1 < b1) copy_ids(tile + 1, ls);
         if constexpr (LMAX == 2) {
           stage_region(std::integral_constant<int, 8 * H * ES / 16>{}, std::integral_constant<int, H>{}, wb);
           stage_region(std::integral_constant<int, H * ES / 16>{}, std::integral_constant<int, 0>{}, wb + 16 * 8 * H * ES);
@@ -1075,7 +1089,7 @@ static int msg_ensure_device(e3_msg_plan* P) {
     (void)hipFree(d);
     return E3_ERR_HIP;
   }
-  const size_t lds = (size_t)(P->k->lds_tab + 4 * P->k->lds_wave) * 4;
+  const size_t lds = (size_t)(P->k->lds_tab + 4 * P->k->lds_wave) * 4 + 4 * 256;  // + edge-id buffers
   for (int io = 0; io < 2; ++io)
     if (P->k->fused[io] &&
         hipFuncSetAttribute(P->k->fused[io], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
@@ -1235,7 +1249,7 @@ int e3_msg_forward(e3_msg_plan* P, const void* h, int64_t ld_h, int64_t N, const
   nwg = std::max(8, (nwg + 7) / 8 * 8);
   int blk = tiles_per_block > 0 ? tiles_per_block : 4;  // default: 64 edges (2-3 dst nodes) per wave block
   if (blk > (1 << 16)) blk = 1 << 16;
-  const size_t lds = (size_t)(k.lds_tab + 4 * k.lds_wave) * 4;
+  const size_t lds = (size_t)(k.lds_tab + 4 * k.lds_wave) * 4 + 4 * 256;
   void* args[] = {&h, &ld_h, &pos4, &src, &dst, &E, &packed, &premix, &in_scale, &out, &ld_out, &blk};
   if (hipLaunchKernel(k.fused[io], dim3(nwg), dim3(256), args, lds, s) != hipSuccess) return E3_ERR_HIP;
   return E3_OK;
