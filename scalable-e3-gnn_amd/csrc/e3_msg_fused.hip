@@ -710,16 +710,18 @@ __global__ __launch_bounds__(256, msg_waves_per_simd(LMAX, TT)) void msg_fused_k
   };
 
   // The edge ids of a tile (16 src, 16 dst) are copied into LDS one tile ahead by a 4-byte LDS-DMA issued together with the
-  // previous tile's gather copies (lanes 0-15: src, 16-31: dst; the upper half repeats them): they land under the wait the
+  // previous tile's gather copies (lanes 0-15: src, 16-31: dst): they land under the wait the
   // gather needs anyway and occupy no register across the products.  (As prefetched VGPRs they were spilled right after
   // the load -- `global_load; s_waitcnt vmcnt(0); scratch_store`, twice per tile -- and reloaded behind the atomics.)
   auto copy_ids = [&](int tile, int ln) {
-    const int row0 = tile * 16;
-    const int nrows = Ei - row0 < 16 ? Ei - row0 : 16;
+    const int row0 = __builtin_amdgcn_readfirstlane(tile * 16);  // (pinned to SGPRs: as vector induction variables they
+    const int nrows = __builtin_amdgcn_readfirstlane(Ei - row0 < 16 ? Ei - row0 : 16);  // get spilled and reloaded here)
     const int jl = ln & 15;
     const int e = row0 + (jl < nrows ? jl : nrows - 1);
-    const int32_t* p = ((ln & 16) ? dst : src) + e;
-    __builtin_amdgcn_global_load_lds((glb_void_t*)p, (lds_void_t*)idbuf, 4, 0, 0);
+    // two exec-masked copies with scalar bases (a per-lane choice between the two pointers becomes a 64-bit VGPR select
+    // whose operands get hoisted and spilled)
+    if (ln < 16) __builtin_amdgcn_global_load_lds((glb_void_t*)(src + e), (lds_void_t*)idbuf, 4, 0, 0);
+    else if (ln < 32) __builtin_amdgcn_global_load_lds((glb_void_t*)(dst + e), (lds_void_t*)idbuf, 4, 0, 0);
   };
   // outer = this workgroup's chunks, inner = the tiles of this wave's block of the chunk.
   // (A workgroup barrier per tile, so that the waves share one weight stream through L1, measured 26.9 vs 26.5 ms.)
@@ -736,14 +738,14 @@ __global__ __launch_bounds__(256, msg_waves_per_simd(LMAX, TT)) void msg_fused_k
       wave_sync_lds();
     }
     for (int tile = b0; tile < b1; ++tile) {
-      const int row0 = tile * 16;
-      const int nrows = Ei - row0 < 16 ? Ei - row0 : 16;
+      const int row0 = __builtin_amdgcn_readfirstlane(tile * 16);
+      const int nrows = __builtin_amdgcn_readfirstlane(Ei - row0 < 16 ? Ei - row0 : 16);
       int lt;  // lane id, regenerated per tile (the kernel-level copy is spilled across the products)
       asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lt));
       const int sid = idbuf[lt & 15], did = idbuf[16 + (lt & 15)];
       // per-tile opaque copies of loop-invariant addresses: without them LICM hoists ~50 table reads (200 registers) and
       // the block addresses out of the tile loop and spills them
-      uint32_t woff = lane * 16;
+      uint32_t woff = lt * 16;
       int tab0 = 0;
       asm volatile("" : "+v"(woff), "+v"(tab0));
       const float *n1p = n1tab + tab0, *n2p = n2tab + tab0, *wdp = wdtab + tab0;
