@@ -627,7 +627,10 @@ constexpr int msg_waves_per_simd(int lmax, int tt) {
 }
 
 template <int LMAX, int TT, bool IO16>
-__global__ __launch_bounds__(256, msg_waves_per_simd(LMAX, TT)) void msg_fused_kernel(
+// (waves per SIMD fixed from both sides: with the minimum alone the scheduler of a small instantiation -- l_max = 1 needs ~120
+// registers -- trades its load / compute overlap for an occupancy the launch does not use: 6.7 -> 8.7 ms)
+__global__ __launch_bounds__(256, msg_waves_per_simd(LMAX, TT))
+__attribute__((amdgpu_waves_per_eu(msg_waves_per_simd(LMAX, TT), msg_waves_per_simd(LMAX, TT)))) void msg_fused_kernel(
     const void* __restrict__ hv, int64_t ldh, const float4* __restrict__ pos4, const int32_t* __restrict__ src,
     const int32_t* __restrict__ dst, int64_t E, const float* __restrict__ packed, const float* __restrict__ U,
     const float* __restrict__ in_scale, float* __restrict__ out, int64_t ldo, int blk) {
@@ -749,7 +752,7 @@ __global__ __launch_bounds__(256, msg_waves_per_simd(LMAX, TT)) void msg_fused_k
       int tab0 = 0;
       asm volatile("" : "+v"(woff), "+v"(tab0));
       const float *n1p = n1tab + tab0, *n2p = n2tab + tab0, *wdp = wdtab + tab0;
-      const int sd = j < nrows ? did : -1;
+      const int sd = (lt & 15) < nrows ? did : -1;
 
       // ---- stage the 16 h[src] rows by 16-byte LDS-DMA (the per-lane source address is the gather).  LDS image per wave:
       //      l_max 2: region A [row][1o | 2e] (2 H units of 16 bytes per row) then region B [row][0e] (H / 4 units);
@@ -823,6 +826,11 @@ __global__ __launch_bounds__(256, msg_waves_per_simd(LMAX, TT)) void msg_fused_k
 
       // ---- tensor product #1: x from the staged rows, dst half as accumulator initial values ----
       {
+        // (every phase regenerates the lane id it needs: v_mbcnt costs two instructions, a lane-derived value kept across
+        // the products costs a register there or a scratch reload here)
+        int LL;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(LL));
+        const int j = LL & 15, g = LL >> 4;
         TpCtx cx;
         cx.w = wrsrc;
         cx.wrole = 0;
@@ -850,6 +858,9 @@ __global__ __launch_bounds__(256, msg_waves_per_simd(LMAX, TT)) void msg_fused_k
       // (norm1 already carries 1 / (sw1 xs)); row scale for the fp16 split: max |m| of the lane's edge -> 2^10
       float amax = 0.f;
       {
+        int LL;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(LL));
+        const int g = LL >> 4;
         const f32x4* nt = reinterpret_cast<const f32x4*>(n1p) + g;  // slot s at nt[4 s]
         auto gate_block = [&](auto dtag, auto& acc, const int slot, const int gslot) {
           constexpr int Dc = decltype(dtag)::value;
@@ -896,7 +907,9 @@ __global__ __launch_bounds__(256, msg_waves_per_simd(LMAX, TT)) void msg_fused_k
       // ---- park the (scaled) messages: slot q of lane l at wbuf[(q * 64 + l) * 4] ----
       wave_sync_lds();
       {
-        f32x4* pk = reinterpret_cast<f32x4*>(wbuf) + lane;
+        int LL;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(LL));
+        f32x4* pk = reinterpret_cast<f32x4*>(wbuf) + LL;
         auto sc4 = [&](const f32x4 v) {
           if constexpr (IO16) {  // bf16 storage: the messages between the two products are bf16 values
             f32x4 o;
@@ -936,7 +949,9 @@ __global__ __launch_bounds__(256, msg_waves_per_simd(LMAX, TT)) void msg_fused_k
       {
         TpCtx cx;
         cx.w = wrsrc; cx.wrole = G::nblk() * 2048; cx.woff = woff; cx.ud = nullptr; cx.wd = nullptr; cx.dsc = 0.f;
-        const f32x4* pk = reinterpret_cast<const f32x4*>(wbuf) + lane;
+        int LL;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(LL));
+        const f32x4* pk = reinterpret_cast<const f32x4*>(wbuf) + LL;
         auto xload = [&](auto l1tag, int ks, auto& x) {
           constexpr int L1 = decltype(l1tag)::value, D1 = 2 * L1 + 1;
           constexpr int S0 = L1 == 0 ? 0 : L1 == 1 ? TT : 4 * TT;  // first parked slot of degree L1
@@ -960,6 +975,9 @@ __global__ __launch_bounds__(256, msg_waves_per_simd(LMAX, TT)) void msg_fused_k
       //      dead from here on), lane = output column walks the 16 rows and adds runs of equal dst; the last run is carried
       //      into the wave's next tile ----
       {
+        int LL;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(LL));
+        const int j = LL & 15, g = LL >> 4;
         const f32x4* nt2 = reinterpret_cast<const f32x4*>(n2p) + g;
         wave_sync_lds();
         float* wp = wbuf + j * RS + 4 * g;
@@ -1077,6 +1095,7 @@ struct e3_msg_plan {
   int K1[3], K2[3], M[3];
   MsgPackDesc* d_desc = nullptr;
   int device = -1;
+  int grid[2] = {0, 0};  // workgroups of a full launch per storage type: CUs x resident workgroups per CU (occupancy query)
   std::mutex mu;
 };
 
@@ -1092,12 +1111,20 @@ static int msg_ensure_device(e3_msg_plan* P) {
     return E3_ERR_HIP;
   }
   const size_t lds = (size_t)(P->k->lds_tab + 4 * P->k->lds_wave) * 4 + 4 * 256;  // + edge-id buffers
-  for (int io = 0; io < 2; ++io)
-    if (P->k->fused[io] &&
-        hipFuncSetAttribute(P->k->fused[io], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cur) != hipSuccess || cus <= 0) cus = 256;
+  for (int io = 0; io < 2; ++io) {
+    if (!P->k->fused[io]) continue;
+    // The grid fills the chip exactly once: what the registers the compiler ended up with and the LDS image allow per CU
+    // (2 workgroups for H = 32, l_max = 2; the small instantiations fit 3-4), not a number assumed at compile time.
+    int per_cu = 0;
+    if (hipFuncSetAttribute(P->k->fused[io], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, P->k->fused[io], 256, lds) != hipSuccess || per_cu < 1) {
       (void)hipFree(d);
       return E3_ERR_HIP;
     }
+    P->grid[io] = cus * (per_cu < 4 ? per_cu : 4);
+  }
   P->device = cur;
   P->d_desc = d;
   return E3_OK;
@@ -1246,7 +1273,7 @@ int e3_msg_forward(e3_msg_plan* P, const void* h, int64_t ld_h, int64_t N, const
   if (!accumulate) E3_HIP_CHECK(hipMemset2DAsync(out, (size_t)ld_out * 4, 0, (size_t)k.D * 4, (size_t)N, s));
   if (E == 0) return E3_OK;
   const int64_t ntiles = (E + 15) / 16;
-  int nwg = 256 * k.waves_per_simd;  // 4 waves per workgroup; waves_per_simd workgroups per CU
+  int nwg = P->grid[io];  // 4 waves per workgroup, every CU filled once
   nwg = (int)std::min<int64_t>(nwg, (ntiles + 3) / 4);
   nwg = std::max(8, (nwg + 7) / 8 * 8);
   int blk = tiles_per_block > 0 ? tiles_per_block : 4;  // default: 64 edges (2-3 dst nodes) per wave block
