@@ -73,6 +73,50 @@ def test_fused_message_feature_scales():
         assert err < 3e-6, (s, err)
 
 
+def test_fused_message_edge_subsets():
+    """Explicit dst-sorted edge lists (the `edges=` form the sharded path uses) whose shapes stress the tile / run logic:
+    fewer than 16 edges, a tail tile, one dst run that spans many tiles and several waves' blocks (the centre of a dense
+    ball), and strided subsets that put many short runs into every tile.  Reference: the unfused chain's per-edge messages,
+    summed with index_add_ over the same edges."""
+    torch.manual_seed(21)
+    gen = torch.Generator().manual_seed(8)
+    N = 1200
+    pos = torch.rand(N, 3, generator=gen)
+    pos[:300] = 0.5 + 0.02 * torch.randn(300, 3, generator=gen)        # a dense ball: nodes with hundreds of neighbours
+    g = radius_graph(pos.to(DEV), 0.06, [0, 0, 0], [1, 1, 1])
+    E = g.num_edges
+    deg = (g.rowptr[1:] - g.rowptr[:-1])
+    assert int(deg.max()) > 150 and E > 20000
+    layer = SEGNNLayer(32, 2).to(DEV)
+    h = torch.randn(N, 288, device=DEV)
+    Y, d, A = ops.edge_geometry(g, lmax=2)
+    with torch.no_grad():
+        for tp in (layer.msg1, layer.msg2):
+            tp.exact = True
+        m = ops.gather_concat(h, g, d)
+        m = layer._gate(layer.msg1(m, Y))
+        m = layer._gate(layer.msg2(m, Y))                               # [E, 288] per-edge messages
+        hub = int(deg.argmax())
+        lo, hi = int(g.rowptr[hub]), int(g.rowptr[hub + 1])
+        ar = torch.arange(E, device=DEV)
+        subsets = {
+            "one edge": ar[:1], "15 edges": ar[:15], "17 edges": ar[:17], "33 edges": ar[100:133],
+            "hub only": ar[lo:hi], "hub + neighbours": ar[max(0, lo - 5):min(E, hi + 7)],
+            "every 3rd": ar[::3], "every 7th": ar[3::7], "all": ar,
+        }
+        for name, sel in subsets.items():
+            src, dst = g.src[sel].contiguous(), g.dst[sel].contiguous()
+            want = torch.zeros(N, 288, device=DEV).index_add_(0, dst.long(), m[sel])
+            for tpb in (0, 1):
+                layer._msg.tiles_per_block = tpb
+                got = layer._msg.forward(h, g, layer.msg1, layer.msg2, edges=(src, dst))
+                err = float((got - want).abs().max() / want.abs().max())
+                assert err < 3e-6, (name, tpb, err)
+                touched = torch.zeros(N, dtype=torch.bool, device=DEV)
+                touched[dst.long()] = True
+                assert float(got[~touched].abs().max()) == 0.0, name   # rows without a selected edge stay exactly zero
+
+
 def test_fused_message_empty_graph():
     pos = torch.rand(50, 3, generator=torch.Generator().manual_seed(1))
     g = radius_graph(pos.to(DEV), 1e-4, [0, 0, 0], [1, 1, 1])

@@ -1,2 +1,1 @@
-E3_EXP_LIB=w2u2 timeout -k 10 200 python tools/msg_micro.py 2>&1 | grep "ms/launch" >> gpurun_out/stamps.txt
-timeout -k 10 200 python tools/msg_micro.py 2>&1 | grep "ms/launch" >> gpurun_out/stamps.txt
+timeout -k 10 600 python -m pytest tests/test_msg_fused_gpu.py -x -q > gpurun_out/abl_tests.log 2>&1; echo "rc=$?" >> gpurun_out/abl_tests.log
