@@ -293,6 +293,10 @@ int e3_tp_forward_fused_scatter(const e3_tp_plan* plan, const e3_tp_segment* seg
  *   accumulate != 0: a second edge list for the SAME h rows of the dst nodes (e.g. the halo's boundary edges after the
  *            interior ones): out keeps its contents (premix is reused: it depends on dst rows only)
  *   tiles_per_block: consecutive 16-edge tiles a wave processes before it jumps to its workgroup's next chunk (0 = 4)
+ *   E      : edges of this call, dst-sorted (src / dst int32); E <= 2^31 - 17 (E3_ERR_INVALID_ARG beyond: the edge ids are
+ *            int32 and the kernel's tile arithmetic is 32-bit)
+ *   The launch fills the device once: CUs x the workgroups per CU that hipOccupancyMaxActiveBlocksPerMultiprocessor reports
+ *   for the kernel's registers and LDS image (queried at the plan's first use).
  * One plan belongs to the device current at its first use.
  * ================================================================================================= */
 typedef struct e3_msg_plan e3_msg_plan;
