@@ -640,7 +640,8 @@ __attribute__((amdgpu_waves_per_eu(msg_waves_per_simd(LMAX, TT), msg_waves_per_s
   float* lds = reinterpret_cast<float*>(smem_raw);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int j = lane & 15, g = lane >> 4;
+  // (j = lane & 15 = the lane's edge, g = lane >> 4 = its channel group: every phase of the tile loop derives them from a
+  // regenerated lane id, see item "nothing waits behind the atomics" in DESIGN.md §4.1)
 
   // workgroup tables: norm1 (x 1/xs), norm2, d-term weights
   float* n1tab = lds;
