@@ -552,6 +552,9 @@ __global__ __launch_bounds__(256) void msg_premix_kernel(const void* __restrict_
   const int64_t wave0 = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
   const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
   const float xs = (!IO16 && in_scale) ? in_scale[0] : 1.0f;
+  constexpr bool STAGE = G::KS == 1;  // (two K steps: the 6 weight blocks of a scalar path would take 96 registers)
+  __shared__ __align__(16) float stage_all[STAGE ? 4 * 16 * (6 * 16 + 4) : 4];
+  float* stage = stage_all + (STAGE ? ((threadIdx.x >> 6) * 16 * (6 * 16 + 4)) : 0);
   TpCtx cx;
   cx.w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(packed + G::o_w), 0, 3 * G::nblk() * 2048, 0x00020000);
   cx.wrole = 2 * G::nblk() * 2048;  // role 2
@@ -587,21 +590,53 @@ __global__ __launch_bounds__(256) void msg_premix_kernel(const void* __restrict_
         constexpr int L2 = decltype(l2tag)::value, L3 = decltype(l3tag)::value;
         if constexpr (G::ok(L1, L2, L3)) {
           constexpr int T = G::T(L3), B0 = G::blk(L1, L2, L3), U0 = G::uoff(L1, L2, L3);
+          if constexpr (STAGE) {
+            // Component-outer: the path's T weight blocks stay in registers, each component's [16 nodes][T x 16 channels]
+            // block is transposed through LDS and leaves as 16-byte units that are CONTIGUOUS per node row (128 or 384
+            // bytes) -- the direct form below stores 64-byte pieces, and the launch runs at the per-CU rate of such stores.
+            uint4 wh[T][G::KS], wl[T][G::KS];
 #pragma unroll
-          for (int t = 0; t < T; ++t) {
-            f32x4 u[D1];
+            for (int t = 0; t < T; ++t)
 #pragma unroll
-            for (int a = 0; a < D1; ++a) u[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+              for (int ks = 0; ks < G::KS; ++ks) load_w<IO16>(cx, B0 + ks * T + t, wh[t][ks], wl[t][ks]);
+            constexpr int RSP = T * 16 + 4, UPR = T * 4;  // stage row stride (floats), 16-byte units per row
 #pragma unroll
-            for (int ks = 0; ks < G::KS; ++ks) {
-              uint4 ah, al;
-              load_w<IO16>(cx, B0 + ks * T + t, ah, al);
+            for (int a = 0; a < D1; ++a) {
 #pragma unroll
-              for (int a = 0; a < D1; ++a) u[a] = mma3<IO16>(ah, al, xh[ks][a], xl[ks][a], u[a]);
+              for (int t = 0; t < T; ++t) {
+                f32x4 u = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < G::KS; ++ks) u = mma3<IO16>(wh[t][ks], wl[t][ks], xh[ks][a], xl[ks][a], u);
+                *reinterpret_cast<f32x4*>(stage + j * RSP + t * 16 + 4 * g) = u;
+              }
+              wave_sync_lds();
+#pragma unroll
+              for (int it = 0; it < (16 * UPR + 63) / 64; ++it) {
+                const int unit = it * 64 + lane, row = unit / UPR, col = unit - row * UPR;
+                const int64_t nn = tile * 16 + row;
+                if (unit < 16 * UPR && nn < N)
+                  *reinterpret_cast<f32x4*>(U + nn * (int64_t)G::UD + U0 + a * T * 16 + col * 4) =
+                      *reinterpret_cast<const f32x4*>(stage + row * RSP + col * 4);
+              }
+              wave_sync_lds();
             }
-            if (ok) {
+          } else {
 #pragma unroll
-              for (int a = 0; a < D1; ++a) *reinterpret_cast<f32x4*>(urow + U0 + (a * T + t) * 16) = u[a];
+            for (int t = 0; t < T; ++t) {
+              f32x4 u[D1];
+#pragma unroll
+              for (int a = 0; a < D1; ++a) u[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+              for (int ks = 0; ks < G::KS; ++ks) {
+                uint4 ah, al;
+                load_w<IO16>(cx, B0 + ks * T + t, ah, al);
+#pragma unroll
+                for (int a = 0; a < D1; ++a) u[a] = mma3<IO16>(ah, al, xh[ks][a], xl[ks][a], u[a]);
+              }
+              if (ok) {
+#pragma unroll
+                for (int a = 0; a < D1; ++a) *reinterpret_cast<f32x4*>(urow + U0 + (a * T + t) * 16) = u[a];
+              }
             }
           }
         }
