@@ -81,8 +81,27 @@ def cpu_baseline(args, state):
     return ({"value": n / dt, "unit": "particles/s", "cores": cores, "kind": "port", "seconds": dt,
              "sample": desc + "; every tensor product in the reference's op pattern (gather -> products -> cat -> matmul -> "
                               "column scatter -> norm, its l<=2 generalisation when lmax=2)"},
-            {"value": n / dtb, "unit": "particles/s", "cores": cores, "kind": "port", "seconds": dtb,
+            {"value": n / dtb, "unit": "particles/s", "cores": cores, "kind": "best_effort", "seconds": dtb,
              "sample": desc + "; best-effort CPU formulation (contiguous slices, GEMM on raw channels, einsum with the coupling)"})
+
+
+def spawn_ranks(n):
+    """One child process per rank (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as torch.distributed.run would set them);
+    rank 0's JSON line goes to this process's stdout.  Returns the worst child return code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
 
 
 def roofline_of(dom_tag, dom, traffic_file):
@@ -139,6 +158,10 @@ def main():
     from scalable_e3_gnn_amd.radius_graph import radius_graph
     from scalable_e3_gnn_amd.segnn import SEGNN
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as plain `python bench.py --gpus N`: this process becomes the launcher of its N ranks.  It has not touched
+        # the GPU (no HIP call so far), starts the ranks as child processes and exits with their worst return code.
+        raise SystemExit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -292,11 +292,16 @@ int e3_tp_forward_fused_scatter(const e3_tp_plan* plan, const e3_tp_segment* seg
  *   out    : [N, ld_out] fp32, columns [H | 3 H | 5 H]; zero-filled by the call unless accumulate != 0
  *   accumulate != 0: a second edge list for the SAME h rows of the dst nodes (e.g. the halo's boundary edges after the
  *            interior ones): out keeps its contents (premix is reused: it depends on dst rows only)
- *   tiles_per_block: consecutive 16-edge tiles a wave processes before it jumps to its workgroup's next chunk (0 = 4)
+ *   tiles_per_block: work granularity (0 = default).  hidden = 32, l_max = 2, fp32: the weights-stationary kernel
+ *            (e3_msg_ws.hip: one workgroup of 8 waves per CU walks chunks of 16 * tiles_per_block edges, default 256 edges,
+ *            dealt round-robin to the workgroups of an XCD; tiles inside a chunk are cut at dst-run boundaries: <= 16 edges,
+ *            <= 2 runs).  Other shapes, or tiles_per_block < 0: the one-wave-per-tile kernel (e3_msg_fused.hip), where
+ *            |tiles_per_block| = consecutive 16-edge tiles a wave processes before it jumps to its workgroup's next chunk (0 = 4)
  *   E      : edges of this call, dst-sorted (src / dst int32); E <= 2^31 - 17 (E3_ERR_INVALID_ARG beyond: the edge ids are
  *            int32 and the kernel's tile arithmetic is 32-bit)
- *   The launch fills the device once: CUs x the workgroups per CU that hipOccupancyMaxActiveBlocksPerMultiprocessor reports
- *   for the kernel's registers and LDS image (queried at the plan's first use).
+ *   The launch fills the device once: one 512-thread workgroup per CU (weights-stationary kernel), or CUs x the workgroups
+ *   per CU that hipOccupancyMaxActiveBlocksPerMultiprocessor reports for the kernel's registers and LDS image (queried at
+ *   the plan's first use).
  * One plan belongs to the device current at its first use.
  * ================================================================================================= */
 typedef struct e3_msg_plan e3_msg_plan;

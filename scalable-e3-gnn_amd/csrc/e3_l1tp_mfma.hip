@@ -112,12 +112,11 @@ int mfma_plan_init(e3_l1tp_plan* P) {
   // preference: weights in LDS, then double buffering with >= 3 waves, else single buffer with more waves
   d.w_in_lds = waves_for(tables + wbytes, 1) >= 2 ? 1 : 0;
   size_t fixed = tables + (d.w_in_lds ? wbytes : 0);
-  int nw2 = waves_for(fixed, 2), nw1 = waves_for(fixed, 1);
-  const char* force = getenv("E3_MFMA_NBUF");  // tuning knob: force single (1) / double (2) buffering
-  bool want2 = force ? (atoi(force) == 2 && nw2 >= 1) : false;  // measured: more waves beats prefetch (profiles/r01)
-  if (want2) { d.nbuf = 2; d.nwaves = nw2; }
-  else { d.nbuf = 1; d.nwaves = nw1; }
-  if (const char* mw = getenv("E3_MFMA_MAXWAVES")) d.nwaves = std::max(1, std::min(d.nwaves, atoi(mw)));
+  const int nw1 = waves_for(fixed, 1);
+  // single buffering with as many waves as the LDS budget admits: measured faster than double buffering with fewer waves
+  // (profiles/r01_l1tp_micro_*); the library reads no environment variables
+  d.nbuf = 1;
+  d.nwaves = nw1;
   m->usable = d.nwaves >= 1 && d.wtotal > 0;
   m->lds_bytes = fixed + (size_t)d.nwaves * (in_tile * d.nbuf + out_tile);
   return E3_OK;

@@ -55,16 +55,21 @@ class _L1TPFunction(torch.autograd.Function):
     def forward(ctx, mod: "L1TensorProduct", in1: Tensor, in2: Tensor, *weights: Optional[Tensor]):
         out = mod._hip_forward(in1, in2)
         ctx.mod = mod
-        ctx.save_for_backward(in1, in2)
+        # the weights travel through save_for_backward as well: autograd's version counters then catch an in-place
+        # update between forward and backward, and backward differentiates the values the forward used
+        ctx.wpresent = [w is not None for w in weights]
+        ctx.save_for_backward(in1, in2, *[w for w in weights if w is not None])
         return out
 
     @staticmethod
     def backward(ctx, grad_out: Tensor):
         mod = ctx.mod
-        in1, in2 = ctx.saved_tensors
+        in1, in2, *saved_w = ctx.saved_tensors
+        it = iter(saved_w)
+        ws = [next(it) if present else None for present in ctx.wpresent]
         need_in1, need_in2 = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         need_w = any(ctx.needs_input_grad[3:])
-        g_in1, g_in2, g_w = mod._hip_backward(in1, in2, grad_out.contiguous(), need_in1, need_in2, need_w)
+        g_in1, g_in2, g_w = mod._hip_backward(in1, in2, grad_out.contiguous(), need_in1, need_in2, need_w, weights=ws)
         gw_out = []
         for i, c in enumerate(_CLS):
             gw_out.append(g_w[c] if (ctx.needs_input_grad[3 + i] and g_w is not None) else None)
@@ -222,7 +227,11 @@ class L1TensorProduct(Module):
         """Packed weight buffer for the kernels; rebuilt when any parameter/buffer changed."""
         ws, ns = self._weights(), self._norms()
         key = (dtype, device) + tuple((t.data_ptr(), t._version) if t is not None else None for t in ws + ns)
+        stream = torch.cuda.current_stream(device)
         if self._packed is not None and self._packed_key == key:
+            # packed on another stream: this stream waits for that pack launch (same rule as message.py / tensor_product.py)
+            if self._packed_stream != stream.cuda_stream:
+                stream.wait_event(self._packed_event)
             return self._packed
         lib = _lib.load()
         code = _lib.dtype_code(dtype)
@@ -236,10 +245,11 @@ class L1TensorProduct(Module):
         packed = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
         wsc = [w.detach().contiguous() if w is not None else None for w in ws]
         nsc = [n.detach().contiguous() if n is not None else None for n in ns]
-        stream = torch.cuda.current_stream(device).cuda_stream
         _lib.check(lib.e3_l1tp_pack_weights(plan.handle(device), _lib.ptr4(wsc), _lib.ptr4(nsc), code,
-                                            packed.data_ptr(), stream), "e3_l1tp_pack_weights")
-        self._packed, self._packed_key = packed, key
+                                            packed.data_ptr(), stream.cuda_stream), "e3_l1tp_pack_weights")
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        self._packed, self._packed_key, self._packed_stream, self._packed_event = packed, key, stream.cuda_stream, ev
         return packed
 
     def _hip_forward(self, in1: Tensor, in2: Tensor) -> Tensor:
@@ -270,11 +280,11 @@ class L1TensorProduct(Module):
                               kernel="e3::l1tp_fwd_mfma_kernel")
         return out
 
-    def _hip_backward(self, in1, in2, grad_out, need_in1, need_in2, need_w):
+    def _hip_backward(self, in1, in2, grad_out, need_in1, need_in2, need_w, weights=None):
         lib = _lib.load()
         B = in1.shape[0]
         dtype, device = in1.dtype, in1.device
-        ws, ns = self._weights(), self._norms()
+        ws, ns = (weights if weights is not None else self._weights()), self._norms()
         g_in1 = torch.empty_like(in1, memory_format=torch.contiguous_format) if need_in1 else None
         g_in2 = torch.empty_like(in2, memory_format=torch.contiguous_format) if need_in2 else None
         g_w = {c: (torch.empty_like(w) if (need_w and w is not None) else None) for c, w in zip(_CLS, ws)}

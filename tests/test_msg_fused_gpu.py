@@ -44,7 +44,7 @@ def test_fused_message_matches_unfused_chain(lmax, H, N, k):
     with torch.no_grad():
         want = _unfused(layer, h, g, Y, d)
         scale = float(want.abs().max())
-        for tpb in (0, 1, 3):
+        for tpb in (0, 1, 3, -4):   # >= 0: weights-stationary kernel where it exists (chunks of 16 tpb edges); < 0: one wave per tile
             layer._msg.tiles_per_block = tpb
             got = layer._msg.forward(h, g, layer.msg1, layer.msg2)
             err = float((got - want).abs().max()) / scale
@@ -107,7 +107,7 @@ def test_fused_message_edge_subsets():
         for name, sel in subsets.items():
             src, dst = g.src[sel].contiguous(), g.dst[sel].contiguous()
             want = torch.zeros(N, 288, device=DEV).index_add_(0, dst.long(), m[sel])
-            for tpb in (0, 1):
+            for tpb in (0, 1, -1):
                 layer._msg.tiles_per_block = tpb
                 got = layer._msg.forward(h, g, layer.msg1, layer.msg2, edges=(src, dst))
                 err = float((got - want).abs().max() / want.abs().max())
