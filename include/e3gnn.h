@@ -288,7 +288,8 @@ int e3_tp_forward_fused_scatter(const e3_tp_plan* plan, const e3_tp_segment* seg
  *            n1 / n2 = their norm buffers (length M, 3 M, 5 M) or NULL for 1.
  *   premix : N * e3_msg_premix_floats_per_node() floats written by e3_msg_premix (W_dst h per node: the dst half of TP1
  *            does not depend on the edge, so it is contracted once per NODE and enters the edge kernel as the MFMA
- *            accumulator's initial value); call e3_msg_premix(h) before e3_msg_forward on the same h and in_scale
+ *            accumulator's initial value; behind the N table rows: max |h[n] * in_scale| per node, from which the edge kernel
+ *            bounds a row's messages); call e3_msg_premix(h) before e3_msg_forward on the same h and in_scale
  *   out    : [N, ld_out] fp32, columns [H | 3 H | 5 H]; zero-filled by the call unless accumulate != 0
  *   accumulate != 0: a second edge list for the SAME h rows of the dst nodes (e.g. the halo's boundary edges after the
  *            interior ones): out keeps its contents (premix is reused: it depends on dst rows only)

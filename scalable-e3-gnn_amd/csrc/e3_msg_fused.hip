@@ -144,6 +144,32 @@ __global__ void msg_pack_kernel(MsgPackArgs a, const MsgPackDesc* desc, int ndes
       packed[1] = sw1; packed[2] = 1.0f / sw1;
       packed[4] = sw2; packed[5] = 1.0f / sw2;
     }
+    // header[6]: Bw with |gated message of product #1| <= Bw * max|input of the row| (true units):
+    //   |sum_paths sum_a z[a][c] (W^T x)[a][w]| <= kZMax * (column sum of |W|) * max|x|,   kZMax = max over paths of
+    //   max_c sum_a ||C[a][.][c]||_2 * sqrt(2 l2 + 1) = 5 (component-normalised harmonics; oracle/cg.py tables), gates <= 1.
+    // The weights-stationary kernel derives the per-row power-of-two scale of product #2's fp16 (hi, lo) operands from it
+    // (e3_msg_ws.hip); a bound that is loose by up to 2^14 costs no accuracy there.
+    __shared__ uint32_t red[2];
+    float bw = 0.f;
+    for (int l = 0; l <= a.LMAX; ++l) {
+      const int M = l == 0 ? a.M0 : a.H;
+      const int rows = (int)(a.nw1[l] / M);
+      if (threadIdx.x < 2) red[threadIdx.x] = 0u;
+      __syncthreads();
+      float cs = 0.f, nm = 0.f;
+      for (int col = threadIdx.x; col < M; col += blockDim.x) {
+        float sum = 0.f;
+        for (int r = 0; r < rows; ++r) sum += fabsf(rd(a.w1[l], (int64_t)r * M + col));
+        cs = fmaxf(cs, sum);
+      }
+      for (int i = threadIdx.x; i < M * (2 * l + 1); i += blockDim.x) nm = fmaxf(nm, a.n1[l] ? fabsf(rd(a.n1[l], i)) : 1.0f);
+      if (cs > 0.f && cs < INFINITY) atomicMax(&red[0], __builtin_bit_cast(uint32_t, cs));
+      if (nm > 0.f && nm < INFINITY) atomicMax(&red[1], __builtin_bit_cast(uint32_t, nm));
+      __syncthreads();
+      bw = fmaxf(bw, 5.0f * __builtin_bit_cast(float, red[0]) * __builtin_bit_cast(float, red[1]));
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) packed[6] = bw;
   }
 }
 
@@ -378,7 +404,8 @@ __device__ __forceinline__ void tp_core(const TpCtx& cx, const float (&y)[9], XL
 template <int LMAX, int TT, bool IO16>
 __global__ __launch_bounds__(256) void msg_premix_kernel(const void* __restrict__ hv, int64_t ldh, int64_t N,
                                                          const float* __restrict__ packed,
-                                                         const float* __restrict__ in_scale, float* __restrict__ U) {
+                                                         const float* __restrict__ in_scale, float* __restrict__ U,
+                                                         float* __restrict__ hmax) {
   using G = MsgGeom<LMAX, TT>;
   constexpr int ES = IO16 ? 2 : 4;
   const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
@@ -398,6 +425,7 @@ __global__ __launch_bounds__(256) void msg_premix_kernel(const void* __restrict_
     const bool ok = n < N;
     const char* row = reinterpret_cast<const char*>(hv) + (ok ? n : N - 1) * ldh * ES;
     float* urow = U + (ok ? n : N - 1) * (int64_t)G::UD + 4 * g;
+    float rowmax = 0.f;  // max |h[n] * xs| over this lane's channels (joined over the 4 lanes of the node below)
     auto per_l1 = [&](auto l1tag) {
       constexpr int L1 = decltype(l1tag)::value, D1 = 2 * L1 + 1;
       uint4 xh[G::KS][D1], xl[G::KS][D1];
@@ -411,6 +439,10 @@ __global__ __launch_bounds__(256) void msg_premix_kernel(const void* __restrict_
           else
             zero_piece<D1>(p, x);
         }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int aa = 0; aa < D1; ++aa) rowmax = fmaxf(rowmax, fabsf(x[i][aa]));
 #pragma unroll
         for (int a = 0; a < D1; ++a) {
           float f[8];
@@ -484,6 +516,10 @@ __global__ __launch_bounds__(256) void msg_premix_kernel(const void* __restrict_
     per_l1(std::integral_constant<int, 0>{});
     per_l1(std::integral_constant<int, 1>{});
     if constexpr (LMAX == 2) per_l1(std::integral_constant<int, 2>{});
+    // per-node row maximum (scaled units): the weights-stationary edge kernel bounds a row's messages with it
+    rowmax = fmaxf(rowmax, __shfl_xor(rowmax, 16));
+    rowmax = fmaxf(rowmax, __shfl_xor(rowmax, 32));
+    if (hmax && ok && lane < 16) hmax[n] = rowmax;
   }
 }
 
@@ -1060,7 +1096,8 @@ int e3_msg_plan_destroy(e3_msg_plan* P) {
 }
 
 int64_t e3_msg_packed_bytes(const e3_msg_plan* P) { return P ? (P->k->total_floats * 4 + 255) / 256 * 256 : -1; }
-int64_t e3_msg_premix_floats_per_node(const e3_msg_plan* P) { return P ? P->k->UD : -1; }
+// the table row (UD floats) + one float of the per-node row maxima, stored behind the N table rows
+int64_t e3_msg_premix_floats_per_node(const e3_msg_plan* P) { return P ? P->k->UD + 1 : -1; }
 int e3_msg_weight_shape(const e3_msg_plan* P, int tp, int l3, int* rows, int* cols) {
   if (!P || !rows || !cols || l3 < 0 || l3 > 2 || (tp != 1 && tp != 2)) return E3_ERR_INVALID_ARG;
   *rows = tp == 1 ? P->K1[l3] : P->K2[l3];
@@ -1119,7 +1156,8 @@ int e3_msg_premix(e3_msg_plan* P, const void* h, int64_t ld_h, int64_t N, const 
   if (st != E3_OK) return st;
   const int64_t ntiles = (N + 15) / 16;
   const int grid = (int)std::min<int64_t>((ntiles + 3) / 4, 2048);
-  void* args[] = {&h, &ld_h, &N, &packed, &in_scale, &premix};
+  float* hmax = premix + (size_t)N * k.UD;
+  void* args[] = {&h, &ld_h, &N, &packed, &in_scale, &premix, &hmax};
   if (hipLaunchKernel(k.premix[io], dim3(grid), dim3(256), args, 0, (hipStream_t)stream) != hipSuccess) return E3_ERR_HIP;
   return E3_OK;
 }
@@ -1144,7 +1182,7 @@ int e3_msg_forward(e3_msg_plan* P, const void* h, int64_t ld_h, int64_t N, const
   // H = 32, fp32: the weights-stationary kernel (e3_msg_ws.hip); tiles_per_block > 0 = its chunk size in 16-edge units.
   // tiles_per_block < 0 asks for this file's one-wave-per-tile kernel with |tiles_per_block| tiles per wave block.
   if (tiles_per_block >= 0 && msg_ws_supported(P->lmax, P->H, dtype)) {
-    st = msg_ws_launch(P->lmax, P->H, dtype, h, ld_h, pos4, src, dst, E, packed, in_scale, premix, out, ld_out,
+    st = msg_ws_launch(P->lmax, P->H, dtype, h, ld_h, N, pos4, src, dst, E, packed, in_scale, premix, out, ld_out,
                        tiles_per_block > (1 << 20) ? (1 << 24) : tiles_per_block * 16, s);
     if (st != E3_ERR_UNSUPPORTED) return st;
   }

@@ -16,18 +16,25 @@
 // LDS: the gathered h[src] rows, the two pre-mix rows of its (at most two) dst nodes and the positions arrive by LDS-DMA one
 // step ahead; the MFMA B operands are converted ONCE per tile into fp16 (hi, lo) fragments that every wave of a team reads.
 // A step is two phases with one workgroup barrier each, and the two teams are STAGGERED: while one team multiplies, the other
-// converts, so every SIMD always holds one matrix-heavy and one vector-only wave (with both teams in the same kind of phase
-// the two waves of a SIMD competed for the same pipe and a step took the SUM of their issue times: 7.6 k cycles, now ~4 k):
+// does vector / copy work, so every SIMD holds one matrix-heavy and one light wave (with both teams in the same kind of phase
+// the two waves of a SIMD competed for the same pipe and a step took the SUM of their issue times):
 //
-//   phase X(s)   waves 0-2: gathered rows of tile s -> B fragments of product #1, spherical harmonics
-//                wave 3   : look at the ids of tile s + 1, cut the tile (<= 16 edges, <= 2 dst runs), copy its positions and
-//                           pre-mix rows (a row that is already staged for the previous tile is not copied again), ids of s + 2
-//                team 1   : product #2 + gate of tile s - 2 -> out tile
-//   phase Y(s)   team 0   : product #1 + gate of tile s -> gated messages (double buffered)
-//                team 1   : copies of the h[src] rows of tile s + 1 (4-5 per wave), gated messages of tile s - 1 -> B fragments
-//                           of product #2, then the run sums of tile s - 2 (fp32 atomics, one per node, column and chunk)
+//   phase X(s)   waves 0-1: gathered rows of tile s -> B fragments of product #1 (wave p: rows 8 p .. 8 p + 7), harmonics
+//                wave 3   : look at the ids of tile s + 1, cut the tile (<= 16 edges, <= 2 dst runs), copy its positions, row
+//                           maxima and pre-mix rows (a row already staged for the previous tile is not copied again), ids of s + 2
+//                team 1   : product #2 + gate of tile s - 1 -> out tile
+//   phase Y(s)   team 0   : product #1 + gate of tile s -> B fragments of product #2, written directly (below)
+//                waves 4-5: run sums of tile s - 1 (fp32 atomics, one per node, column and chunk)
+//                waves 6-7: copies of the h[src] rows of tile s + 1 (9 x 1 KiB each)
 //
-// Vector-memory instructions per tile: ~26 copies (was 283); nothing in the tile loop waits for a global load.
+// Product #1 -> product #2 without a message buffer: the gated output of product #1 sits in accumulator layout, which IS the
+// B-operand layout of product #2 (k order permuted at pack time), so each wave stores its own 8-byte half of every fragment
+// lane.  The fp16 (hi, lo) split needs one power-of-two scale per edge row that ALL four waves agree on without talking:
+// it is derived from a rigorous bound, |message| <= Bw * max(|h[src]|, |h[dst]|, d) with Bw from the weights (pack time,
+// header[6]) and the per-node row maxima the pre-mix launch leaves behind its table.  The pair (hi, lo) keeps an absolute
+// error of 2^-25 of the scaled range, so a bound that is loose by many binades costs nothing (e3_tp_mfma_core.h: split2_f16).
+//
+// Vector-memory instructions per tile: ~27 copies (was 283); nothing in the tile loop waits for a global load.
 //
 // Tiles are cut adaptively: a tile never spans more than two dst runs (so the pre-mix rows of a tile fit two of the four
 // staged row slots and the segment sum has at most two runs); with dst-sorted edges and ~24 edges per node most tiles are full.
@@ -47,6 +54,10 @@ namespace e3 {
 
 #if E3_WS_STAMP
 __device__ unsigned long long g_ws_stamps[8][4];
+__device__ unsigned long long g_ws_tp[8][8];   // per wave: cycles to the marks inside the tensor product
+#define WS_TPMARK(i) { if (tpm) { const uint32_t t_ = (uint32_t)__builtin_readcyclecounter(); tpm[i] += t_ - tpm0; tpm0 = t_; } }
+#else
+#define WS_TPMARK(i)
 #endif
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -63,8 +74,6 @@ struct Ws {
   static constexpr int FRB = IO16 ? 1024 : 2048;           // bytes per fragment: 64 lanes x 16 B hi (+ lo)
   static constexpr int frag(int l, int a) { return l * l + a; }
   static constexpr int frag_ff(int l) { return NC + l - 1; }
-  static constexpr int NM = NC * TT;                       // message slots (f32x4 per lane): degree l, tile t, component a
-  static constexpr int mslot(int l, int t, int a) { return l * l * TT + (2 * l + 1) * t + a; }
   // gathered rows: region A = [1o | 2e] (8 H elements per row, one row per copy, rows padded by 16 bytes so that the 16-byte
   // column reads of the 16 rows fall on different banks), region B = [0e] rows, linear (8 or 16 rows per copy)
   static constexpr int GA_ROW = 8 * H * ES;
@@ -83,12 +92,17 @@ struct Ws {
   static constexpr int o_ids = o_tinfo + 4 * 32;                        // ring of 4 x (16 src + 16 dst)
   static constexpr int o_idok = o_ids + 4 * 128;                        // ring of 4 flags: the ids of tile t were requested
   static constexpr int o_pos = o_idok + 16;                             // ring of 2 x (16 src + 16 dst) float4
-  static constexpr int o_y = o_pos + 2 * 512;                           // ring of 4 x 16 edges x 12 floats (y[9], d, -, -)
-  static constexpr int o_pmax = o_y + 4 * 768;                          // ring of 2 x 4 roles x 16 edges
-  static constexpr int o_g = o_pmax + 2 * 256;                          // gather image (copied in phase Y, read in phase X)
+  static constexpr int o_hmx = o_pos + 2 * 512;                         // ring of 2 x (16 src + 16 dst) row maxima
+  static constexpr int o_srow = o_hmx + 2 * 128;                        // ring of 2 x 16 row scales of product #2's operands
+  // edge table (ring of 2 tiles x 16 edges x ZT floats): harmonics, distance and the dense couplings z[a][c] = sum_b C[a][b][c] Y[b]
+  // of the four paths whose coupling is not a multiple of one harmonic -- computed ONCE per tile by wave 2 and read by the four
+  // waves of both products (each of them used to recompute its paths' couplings: ~80 vector instructions per wave and product)
+  static constexpr int z_y = 0, z_112 = 12, z_121 = 28, z_211 = 40, z_222 = 56, ZT = 84;
+  static constexpr int o_zt = o_srow + 2 * 64;
+  static constexpr int o_init = o_zt + 2 * 16 * ZT * 4;                 // initial values of the T(0) scalar-type tiles of product #1
+  static constexpr int o_g = o_init + G::T(0) * 1024;                   // gather image (copied in phase Y, read in phase X)
   static constexpr int o_b1 = o_g + G_BYTES;
-  static constexpr int o_m = o_b1 + NFR * FRB;                          // ring of 2 message buffers
-  static constexpr int o_b2 = o_m + 2 * NM * 1024;
+  static constexpr int o_b2 = o_b1 + NFR * FRB;
   static constexpr int o_o = o_b2 + NFR * FRB;
   static constexpr int o_u = o_o + 16 * RS * 4;                         // 4 pre-mix row slots
   static constexpr int total = o_u + 4 * U_ROW;
@@ -193,13 +207,17 @@ __device__ __forceinline__ void ws_load_w(const float* packed, const int prod /*
 #ifndef WS_PF
 #define WS_PF 2
 #endif
+#ifndef WS_PRIO
+#define WS_PRIO 0   // s_setprio of a product wave while it multiplies (0: none; 2 measured 20.4 vs 19.6 ms: the partner waves are near-critical too)
+#endif
 template <int LMAX>
-struct TpItems {
+struct TpItems {  // degrees in DESCENDING order: the largest fold (degree l_max) overlaps the products of the degrees after it
   static constexpr int N = (LMAX + 1) * (LMAX + 1) + LMAX;
-  static constexpr int start(int l) { return l == 0 ? 0 : l * l + l - 1; }          // first item of degree l
-  static constexpr int l1(int i) { return i < start(1) ? 0 : (LMAX < 2 || i < start(2)) ? 1 : 2; }
+  static constexpr int len(int l) { return 2 * l + 1 + (l > 0 ? 1 : 0); }
+  static constexpr int start(int l) { int n = 0; for (int k = LMAX; k > l; --k) n += len(k); return n; }  // first item of degree l
+  static constexpr int l1(int i) { int l = LMAX; while (l > 0 && i >= start(l) + len(l)) --l; return l; }
   static constexpr int a(int i) { const int l = l1(i), k = i - start(l); return k < 2 * l + 1 ? k : -1; }  // -1: feature-first operand
-  static constexpr bool last(int i) { return i + 1 == N || l1(i + 1) != l1(i); }
+  static constexpr bool first(int i) { return i == start(l1(i)); }
 };
 
 template <int LMAX, int TT, int ROLE, bool FIRST, bool IO16>
@@ -210,22 +228,33 @@ struct TpRun {
   using IT = TpItems<LMAX>;
   static constexpr int LV = O::LV, t = O::t, tG = O::tG, tS = O::tS;
   static constexpr bool SC = tG >= 0 || tS >= 0;  // owns scalar-type (l3 = 0) tiles
+  static_assert(LMAX == 2, "edge table layout");
 
   const RoleW<O::NW>& w;
   const unsigned char* bfr;
-  const float (&y)[9];
+  const float* zt;         // this lane's row of the edge table
   const float* urow;
   const float* wd;
-  const float dsc;
+  const f32x4* init;       // FIRST: initial values of the scalar-type tiles (+ lane): pre-mix of (l, l, 0), d-term
   f32x4 (&accV)[5];
   f32x4& accG;
   f32x4& accS;
+  float dsc;
   // operand ring and per-degree state (everything indexed at compile time)
   uint4 bh[WS_PF + 1], bl[WS_PF + 1];
   f32x4 uV[3][3][5];       // [l1][l2][a]: mix-first accumulators of the paths into the vector tile
-  f32x4 u0G, u0S;          // path (0, 0, 0) into the scalar-type tiles
-  f32x4 ffG[3][5], ffS[3][5];  // FIRST: pre-mix values of the feature-first paths (l1, l1, 0), folded after the product
-  f32x4 wdV, wdG, wdS;     // FIRST: d-term weights
+  f32x4 wdV;               // FIRST: d-term weights of the vector tile
+  f32x4 yv[3];             // harmonics of this lane's edge (y[0..8], d xs)
+  f32x4 zq[3][3][7];       // [l1][l2][.]: dense coupling of path (l1, l2, LV) as loaded from the table
+#if E3_WS_STAMP
+  uint32_t* tpm = nullptr;
+  uint32_t tpm0 = 0;
+#endif
+  static constexpr int zoff(int l1, int l2) {  // table offset of path (l1, l2, LV); -1: coupling is a multiple of one harmonic
+    return (l1 == 1 && l2 == 1 && LV == 2) ? L::z_112 : (l1 == 1 && l2 == 2 && LV == 1) ? L::z_121
+         : (l1 == 2 && l2 == 1 && LV == 1) ? L::z_211 : (l1 == 2 && l2 == 2 && LV == 2) ? L::z_222 : -1;
+  }
+  __device__ __forceinline__ float yy(const int i) const { return yv[i >> 2][i & 3]; }
 
   template <int I>
   __device__ __forceinline__ void request() {
@@ -244,42 +273,27 @@ struct TpRun {
           if constexpr (LV > 0 && G::ok(L1, L2, LV)) {
             if constexpr (FIRST) uV[L1][L2][a] = *reinterpret_cast<const f32x4*>(urow + G::uoff(L1, L2, LV) + (a * G::T(LV) + t) * 16);
             else uV[L1][L2][a] = zero4;
+            // the path's coupling travels with its first component: consumed after its last one
+            if constexpr (a == 0 && zoff(L1, L2) >= 0) {
+              constexpr int NZ = ((2 * L1 + 1) * (2 * LV + 1) + 3) / 4;
+#pragma unroll
+              for (int q = 0; q < NZ; ++q) zq[L1][L2][q] = *reinterpret_cast<const f32x4*>(zt + zoff(L1, L2) + 4 * q);
+            }
           }
         });
-        if constexpr (L1 == 0) {
-          u0G = zero4; u0S = zero4;
-          if constexpr (FIRST) {
-            if constexpr (tG >= 0) u0G = *reinterpret_cast<const f32x4*>(urow + G::uoff(0, 0, 0) + tG * 16);
-            if constexpr (tS >= 0) u0S = *reinterpret_cast<const f32x4*>(urow + G::uoff(0, 0, 0) + tS * 16);
-            if constexpr (LV > 0) wdV = *reinterpret_cast<const f32x4*>(wd + G::wdoff(LV) + t * 16);
-            if constexpr (tG >= 0) wdG = *reinterpret_cast<const f32x4*>(wd + G::wdoff(0) + tG * 16);
-            if constexpr (tS >= 0) wdS = *reinterpret_cast<const f32x4*>(wd + G::wdoff(0) + tS * 16);
-          }
-        }
-        // the fold values of this degree's feature-first path travel with its first component: consumed a degree later
-        if constexpr (FIRST && L1 > 0 && a == 0 && SC) {
-#pragma unroll
-          for (int c = 0; c < 2 * L1 + 1; ++c) {
-            if constexpr (tG >= 0) ffG[L1][c] = *reinterpret_cast<const f32x4*>(urow + G::uoff(L1, L1, 0) + (c * G::T(0) + tG) * 16);
-            if constexpr (tS >= 0) ffS[L1][c] = *reinterpret_cast<const f32x4*>(urow + G::uoff(L1, L1, 0) + (c * G::T(0) + tS) * 16);
-          }
-        }
+        if constexpr (L1 == 0 && FIRST && LV > 0) wdV = *reinterpret_cast<const f32x4*>(wd + G::wdoff(LV) + t * 16);
       }
     }
   }
 
   template <int I>
   __device__ __forceinline__ void compute() {
-    constexpr int L1 = IT::l1(I), a = IT::a(I), slot = I % (WS_PF + 1), D1 = 2 * L1 + 1;
+    constexpr int L1 = IT::l1(I), a = IT::a(I), slot = I % (WS_PF + 1);
     const uint4 xh = bh[slot], xl = bl[slot];
     if constexpr (a >= 0) {
-      if constexpr (L1 == 0 && FIRST) {  // distance channel of product #1: couples through (0, l, l)
+      if constexpr (L1 == 0 && FIRST && LV > 0) {  // distance channel of product #1: couples through (0, l, l)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if constexpr (LV > 0) uV[0][LV][0][r] = __builtin_fmaf(wdV[r], dsc, uV[0][LV][0][r]);
-          if constexpr (tG >= 0) u0G[r] = __builtin_fmaf(wdG[r], dsc, u0G[r]);
-          if constexpr (tS >= 0) u0S[r] = __builtin_fmaf(wdS[r], dsc, u0S[r]);
-        }
+        for (int r = 0; r < 4; ++r) uV[0][LV][0][r] = __builtin_fmaf(wdV[r], dsc, uV[0][LV][0][r]);
       }
       sfor3([&](auto l2tag) {
         constexpr int L2 = decltype(l2tag)::value;
@@ -288,39 +302,39 @@ struct TpRun {
           uV[L1][L2][a] = mma3<IO16>(w.h[i], w.l[i], xh, xl, uV[L1][L2][a]);
         }
       });
-      if constexpr (L1 == 0) {
-        if constexpr (tG >= 0) u0G = mma3<IO16>(w.h[O::widx(1, 0, 0)], w.l[O::widx(1, 0, 0)], xh, xl, u0G);
-        if constexpr (tS >= 0) u0S = mma3<IO16>(w.h[O::widx(2, 0, 0)], w.l[O::widx(2, 0, 0)], xh, xl, u0S);
+      if constexpr (L1 == 0) {  // path (0, 0, 0): coupling 1 -- straight into the scalar-type tiles
+        if constexpr (tG >= 0) accG = mma3<IO16>(w.h[O::widx(1, 0, 0)], w.l[O::widx(1, 0, 0)], xh, xl, accG);
+        if constexpr (tS >= 0) accS = mma3<IO16>(w.h[O::widx(2, 0, 0)], w.l[O::widx(2, 0, 0)], xh, xl, accS);
       }
     } else if constexpr (SC) {  // feature-first path (L1, L1, 0) into the scalar-type tiles
       if constexpr (tG >= 0) accG = mma3<IO16>(w.h[O::widx(1, L1, L1)], w.l[O::widx(1, L1, L1)], xh, xl, accG);
       if constexpr (tS >= 0) accS = mma3<IO16>(w.h[O::widx(2, L1, L1)], w.l[O::widx(2, L1, L1)], xh, xl, accS);
     }
-    if constexpr (IT::last(I)) {  // ---- end of degree L1: folds ----
-      if constexpr (L1 == 0) {
-        const float z000 = (float)CG<0, 0, 0>::v[0][0][0] * y[0];
+  }
+
+  template <int L1>
+  __device__ __forceinline__ void fold() {  // ---- after the last product of degree L1: accV += sum_a z[a][c] u[a] ----
+    constexpr int D1 = 2 * L1 + 1;
+    sfor3([&](auto l2tag) {
+      constexpr int L2 = decltype(l2tag)::value;
+      if constexpr (LV > 0 && G::ok(L1, L2, LV)) {
+        constexpr int D3 = 2 * LV + 1;
+        if constexpr (zoff(L1, L2) >= 0) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if constexpr (tG >= 0) accG[r] = __builtin_fmaf(u0G[r], z000, accG[r]);
-          if constexpr (tS >= 0) accS[r] = __builtin_fmaf(u0S[r], z000, accS[r]);
-        }
-      } else if constexpr (FIRST && SC) {
-        float zz[D1][1];
-        make_z<L1, L1, 0>(y, zz);
+          for (int c = 0; c < D3; ++c)
 #pragma unroll
-        for (int c = 0; c < D1; ++c)
+            for (int aa = 0; aa < D1; ++aa)
+              if (z_nonzero<L1, L2, LV>(aa, c)) {
+                const float z = zq[L1][L2][(aa * D3 + c) >> 2][(aa * D3 + c) & 3];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            if constexpr (tG >= 0) accG[r] = __builtin_fmaf(ffG[L1][c][r], zz[c][0], accG[r]);
-            if constexpr (tS >= 0) accS[r] = __builtin_fmaf(ffS[L1][c][r], zz[c][0], accS[r]);
-          }
-      }
-      sfor3([&](auto l2tag) {
-        constexpr int L2 = decltype(l2tag)::value;
-        if constexpr (LV > 0 && G::ok(L1, L2, LV)) {
-          constexpr int D3 = 2 * LV + 1;
+                for (int r = 0; r < 4; ++r) accV[c][r] = __builtin_fmaf(uV[L1][L2][aa][r], z, accV[c][r]);
+              }
+        } else {  // (0, l, l) and (l, 0, l): one harmonic times a constant
+          float y9[9];
+#pragma unroll
+          for (int i = 0; i < 9; ++i) y9[i] = yy(i);
           float zz[D1][D3];
-          make_z<L1, L2, LV>(y, zz);
+          make_z<L1, L2, LV>(y9, zz);
 #pragma unroll
           for (int c = 0; c < D3; ++c)
 #pragma unroll
@@ -330,39 +344,59 @@ struct TpRun {
                 for (int r = 0; r < 4; ++r) accV[c][r] = __builtin_fmaf(uV[L1][L2][aa][r], zz[aa][c], accV[c][r]);
               }
         }
-      });
-    }
+      }
+    });
   }
 
+  // One scheduling region per item: the requests of item I + WS_PF, the products of item I and -- at the first item of a
+  // degree -- the fold of the PREVIOUS degree (vector work that depends only on finished products: it fills the issue slots
+  // between this degree's MFMAs).
   template <int I>
   __device__ __forceinline__ void step() {
     request<I + WS_PF>();
     __builtin_amdgcn_sched_barrier(0);
     compute<I>();
-    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (IT::first(I) && IT::l1(I) < LMAX) fold<IT::l1(I) + 1>();
+    if constexpr (I + 1 < IT::N && IT::first(I + 1)) { WS_TPMARK(1 + LMAX - IT::l1(I)) }
     if constexpr (I + 1 < IT::N) step<I + 1>();
+    else { WS_TPMARK(1 + LMAX) fold<0>(); WS_TPMARK(2 + LMAX) }
   }
 
   __device__ __forceinline__ void run() {
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < 5; ++c) accV[c] = zero4;
+    // harmonics of the edge and the initial values of the scalar-type tiles: requested with the first operands
+#pragma unroll
+    for (int q = 0; q < 3; ++q) yv[q] = *reinterpret_cast<const f32x4*>(zt + L::z_y + 4 * q);
     accG = zero4; accS = zero4;
+    if constexpr (FIRST) {
+      if constexpr (tG >= 0) accG = init[64 * tG];
+      if constexpr (tS >= 0) accS = init[64 * tS];
+    }
     request<0>();
     if constexpr (WS_PF >= 2) request<1>();
     if constexpr (WS_PF >= 3) request<2>();
     static_assert(WS_PF >= 1 && WS_PF <= 3, "prefetch distance");
     __builtin_amdgcn_sched_barrier(0);
+    dsc = yv[2][1];
+    WS_TPMARK(0)
     step<0>();
   }
 };
 
 template <int LMAX, int TT, int ROLE, bool FIRST, bool IO16>
-__device__ __forceinline__ void ws_tp(const RoleW<Own<LMAX, TT, ROLE>::NW>& w, const unsigned char* bfr, const float (&y)[9],
-                                      const float* urow, const float* wd, const float dsc,
-                                      f32x4 (&accV)[5], f32x4& accG, f32x4& accS) {
-  TpRun<LMAX, TT, ROLE, FIRST, IO16> r{w, bfr, y, urow, wd, dsc, accV, accG, accS};
+__device__ __forceinline__ void ws_tp(const RoleW<Own<LMAX, TT, ROLE>::NW>& w, const unsigned char* bfr, const float* zt,
+                                      const float* urow, const float* wd, const f32x4* init,
+                                      f32x4 (&accV)[5], f32x4& accG, f32x4& accS, float (&y)[10], uint32_t* tpmarks = nullptr) {
+  TpRun<LMAX, TT, ROLE, FIRST, IO16> r{w, bfr, zt, urow, wd, init, accV, accG, accS};
+#if E3_WS_STAMP
+  r.tpm = tpmarks;
+  r.tpm0 = (uint32_t)__builtin_readcyclecounter();
+#endif
   r.run();
+#pragma unroll
+  for (int i = 0; i < 10; ++i) y[i] = r.yy(i);  // y[9] = distance * xs
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -371,7 +405,7 @@ __device__ __forceinline__ void ws_tp(const RoleW<Own<LMAX, TT, ROLE>::NW>& w, c
 struct WsArgs {
   const void* h; int64_t ldh;
   const float4* pos4; const int32_t* src; const int32_t* dst; int64_t E;
-  const float* packed; const float* U; const float* in_scale; float* out; int64_t ldo;
+  const float* packed; const float* U; const float* hmax; const float* in_scale; float* out; int64_t ldo;
   int chunk;  // edges per chunk (multiple of 16)
 };
 
@@ -390,6 +424,8 @@ __device__ __forceinline__ void ws_run(const WsArgs& A, unsigned char* smem) {
   const float* n2tab = n1tab + G::NS * 16;
   const float* wdtab = n2tab + G::NS * 16;
   const float xs = (!IO16 && A.in_scale) ? A.in_scale[0] : 1.0f;
+  // |message of product #1| <= bwx * (largest scaled input of the row): Bw (true units, header[6]) / xs
+  const float bwx = A.packed[6] * ((!IO16 && A.in_scale) ? A.in_scale[1] : 1.0f);
   const char* hb = reinterpret_cast<const char*>(A.h);
 
   auto tinfo = [&](const int tile) -> TileInfo {  // uniform; tile < 0: none
@@ -419,34 +455,26 @@ __device__ __forceinline__ void ws_run(const WsArgs& A, unsigned char* smem) {
   const int xlo = (int)(blockIdx.x & 7) * e_per_xcd;
   const int xhi = xlo + e_per_xcd < Ei ? xlo + e_per_xcd : Ei;
 
-  // ---- copies of the h[src] rows of a tile into the (single) gather image.  The image is cut by READER: wave 0 alone reads
-  //      the 2e part of region A, wave 1 alone the 1o part and region B, so each of them re-fills its own part for tile s + 1
-  //      right after its last read of tile s -- a whole phase before the barrier that publishes it.  Rows beyond the end of
-  //      the tile are the src rows of the following edges (valid rows; never summed), so only the ids are needed.
-  //      part 0: [2e] (5 H elements per row), part 1: [1o] (3 H elements per row) + region B ([0e], 8 or 16 rows per copy) ----
+  // ---- copies of the h[src] rows of a tile into the gather image (read in phase X, re-filled in phase Y): part p = rows
+  //      8 p .. 8 p + 7 of region A ([1o | 2e], one full 1-KiB row per copy) and piece p of region B (8 [0e] rows).  Rows beyond
+  //      the end of the tile are the src rows of the following edges (valid rows; never summed): only the ids are needed ----
   auto gather_part = [&](const int tile, const int part) {
     const int* ids = reinterpret_cast<const int*>(smem + L::o_ids) + (tile & 3) * 32;
     const uint32_t gb = lds0 + L::o_g;
-    const int off = part == 0 ? 3 * H * ES : 0, lanes = (part == 0 ? 5 : 3) * H * ES / 16;
+    static_assert(L::GA_ROW == 1024 && L::GB_ROW == 128, "copy shapes of the fp32 image");
     // every LDS read first (the copies are asm statements with a memory clobber: a read between two of them stays there and
-    // exposes its latency once per row -- 200 cycles per copy measured); row ids reach the scalar unit by v_readlane
-    constexpr int UPR = L::GB_ROW / 16, RPC = 64 / UPR;  // region B: units per row, rows per copy
+    // exposes its latency once per row); row ids reach the scalar unit by v_readlane
     const int myid = ids[lane & 15];
-    int ridb[16 / RPC];
-#pragma unroll
-    for (int it = 0; it < 16 / RPC; ++it) ridb[it] = part == 1 ? ids[it * RPC + lane / UPR] : 0;
+    const int ridb = ids[8 * part + (lane >> 3)];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int rid = __builtin_amdgcn_readlane(myid, r);
-      const char* rowp = hb + ((int64_t)rid * A.ldh + H) * ES + off;
-      if (lane < lanes) dma16(rowp + lane * 16, sgpr((int)(gb + r * L::GA_STRIDE + off)));
+    for (int k = 0; k < 8; ++k) {
+      const int r = 8 * part + k;
+      const int rid = part == 0 ? __builtin_amdgcn_readlane(myid, k) : __builtin_amdgcn_readlane(myid, 8 + k);
+      const char* rowp = hb + ((int64_t)rid * A.ldh + H) * ES;
+      dma16(rowp + lane * 16, sgpr((int)(gb + r * L::GA_STRIDE)));
     }
-    if (part == 1) {
-#pragma unroll
-      for (int it = 0; it < 16 / RPC; ++it)
-        dma16(hb + (int64_t)ridb[it] * A.ldh * ES + (lane % UPR) * 16, sgpr((int)(gb + L::GA_BYTES + it * 1024)));
-    }
+    dma16(hb + (int64_t)ridb * A.ldh * ES + (lane & 7) * 16, sgpr((int)(gb + L::GA_BYTES + part * 1024)));
   };
   auto ids_requested = [&](const int tile) -> bool {
     return sgpr(reinterpret_cast<const int*>(smem + L::o_idok)[tile & 3]) != 0;
@@ -470,8 +498,8 @@ __device__ __forceinline__ void ws_run(const WsArgs& A, unsigned char* smem) {
       dma4(p, sgpr((int)(lds0 + L::o_ids + (tile & 3) * 128)));
     }
   };
-  // cut tile `tile` (its ids have landed), publish its descriptor, copy its positions and pre-mix rows, request the ids of
-  // the tile after it
+  // cut tile `tile` (its ids have landed), publish its descriptor, copy its positions, row maxima and pre-mix rows, request
+  // the ids of the tile after it
   auto cut = [&](const int tile) {
     int* tip = reinterpret_cast<int*>(smem + L::o_tinfo) + (tile & 3) * 8;
     if (!pok) {
@@ -488,6 +516,9 @@ __device__ __forceinline__ void ws_run(const WsArgs& A, unsigned char* smem) {
     const int n = sgpr(m2 ? (int)__builtin_ctzll(m2) : nmax);
     const int node0 = __builtin_amdgcn_readlane(did, 0);
     const int node1 = n0 < n ? __builtin_amdgcn_readlane(did, n0) : -1;
+    // src / dst id of lane l < 32 (rows beyond the tile repeat its last edge)
+    const int myid = ids[(lane & 16) + ((lane & 15) < n ? (lane & 15) : n - 1)];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     // pre-mix rows: the first run often continues the previous tile's last node -- its row is staged already
     auto alloc = [&](const int avoid) {
       int sl = pnext;
@@ -514,10 +545,10 @@ __device__ __forceinline__ void ws_run(const WsArgs& A, unsigned char* smem) {
     if (lane == 0) {
       tip[0] = pe0; tip[1] = n; tip[2] = n0; tip[3] = node0; tip[4] = node1; tip[5] = sl0; tip[6] = sl1 >= 0 ? sl1 : sl0;
     }
-    // positions: lanes 0-15 src, 16-31 dst
+    // positions and row maxima: lanes 0-15 src, 16-31 dst
     if (lane < 32) {
-      const int id = ids[(lane & 16) + ((lane & 15) < n ? (lane & 15) : n - 1)];
-      dma16(A.pos4 + id, sgpr((int)(lds0 + L::o_pos + (tile & 1) * 512)));
+      dma16(A.pos4 + myid, sgpr((int)(lds0 + L::o_pos + (tile & 1) * 512)));
+      dma4(A.hmax + myid, sgpr((int)(lds0 + L::o_hmx + (tile & 1) * 128)));
     }
     // next tile
     pe0 = sgpr(pe0 + n);
@@ -538,10 +569,10 @@ __device__ __forceinline__ void ws_run(const WsArgs& A, unsigned char* smem) {
   }
   ws_barrier();
 
-  // run-sum state of team 1: column chunk(s) of this wave
+  // run-sum state of waves 4 / 5: column chunks {0, 1, 2} / {3, 4}
   constexpr int NQ = (D + 63) / 64;
-  // waves 4..7 take column chunks {NQ-1}, {NQ-2}, {NQ-3}, {0 .. NQ-4}: the conversion load of waves 4-6 is larger
-  constexpr int Q0 = !TEAM1 ? 0 : (ROLE == 3 ? 0 : NQ - 1 - ROLE), Q1 = !TEAM1 ? 0 : (ROLE == 3 ? NQ - 3 : NQ - ROLE);
+  constexpr bool RSW = TEAM1 && ROLE < 2;
+  constexpr int Q0 = !RSW ? 0 : (ROLE == 0 ? 0 : (NQ + 1) / 2), Q1 = !RSW ? 0 : (ROLE == 0 ? (NQ + 1) / 2 : NQ);
   constexpr int NQW = Q1 - Q0 > 0 ? Q1 - Q0 : 1;
   int cur = -1;
   float carry[NQW];
@@ -557,121 +588,170 @@ __device__ __forceinline__ void ws_run(const WsArgs& A, unsigned char* smem) {
 #pragma unroll
     for (int q = 0; q < NQW; ++q) carry[q] = 0.f;
   };
-  auto load_y = [&](const int tile, float (&y)[9], float& dist) {
-    const f32x4* yp = reinterpret_cast<const f32x4*>(smem + L::o_y + (tile & 3) * 768 + j * 48);
-    const f32x4 ya = yp[0], yb = yp[1], yc = yp[2];
-    y[0] = ya[0]; y[1] = ya[1]; y[2] = ya[2]; y[3] = ya[3]; y[4] = yb[0]; y[5] = yb[1]; y[6] = yb[2]; y[7] = yb[3]; y[8] = yc[0];
-    dist = yc[1];
-  };
-  auto row_scale = [&](const int tile) -> float {  // power-of-two scale of this lane's message row (fp16 split of product #2)
-    if constexpr (IO16) return 1.0f;
-    const float* pm = reinterpret_cast<const float*>(smem + L::o_pmax) + (tile & 1) * 64 + j;
-    const float amax = fmaxf(fmaxf(pm[0], pm[16]), fmaxf(pm[32], pm[48]));
-    return pow2_scale_from_bits(__builtin_bit_cast(uint32_t, amax), 10);
-  };
-
 #if E3_WS_STAMP
+  uint32_t tpmk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   uint32_t st_acc[4] = {0, 0, 0, 0}, st_t = (uint32_t)__builtin_readcyclecounter();
 #define WS_STAMP(i) { const uint32_t t_ = (uint32_t)__builtin_readcyclecounter(); st_acc[i] += t_ - st_t; st_t = t_; }
 #else
+  uint32_t* const tpmk = nullptr;
 #define WS_STAMP(i)
 #endif
-  TileInfo t0 = tinfo(0), t1 = tinfo(-1), t2 = tinfo(-1);
+  TileInfo t0 = tinfo(0), t1 = tinfo(-1);
   for (int s = 0;; ++s) {
-    if (s >= 2 && t2.n == 0) break;
+    if (s >= 1 && t1.n == 0) break;
     WS_STAMP(3)
     // =========================================== phase X ===========================================
     if constexpr (W == 3) {
       cut(s + 1);
     } else if constexpr (!TEAM1) {
-      // ---- gathered rows of tile s -> B fragments of product #1 (wave 0: degree 2, wave 1: degrees 1 and 0) ----
+      // ---- gathered rows of tile s -> B fragments of product #1.  Wave p (0, 1) converts rows 8 p .. 8 p + 7 of every
+      //      degree: lane = (row j8, channel group g, half pc) handles ONE piece (4 channels x all components) per degree,
+      //      i.e. half of a fragment lane's 8 k slots -> 8-byte stores of the hi and the lo halves ----
       if (W <= 1 && t0.n > 0) {
+        const int j8 = lane & 7, gg = (lane >> 3) & 3, pc = lane >> 5, row = 8 * W + j8;
         const unsigned char* gimg = smem + L::o_g;
-        unsigned char* b1 = smem + L::o_b1 + lane * 16;
-        auto put = [&](const int fr, const float (&f)[8]) {
-          uint4 bh, bl;
-          split8<IO16>(f, bh, bl);
-          *reinterpret_cast<uint4*>(b1 + fr * L::FRB) = bh;
-          if constexpr (!IO16) *reinterpret_cast<uint4*>(b1 + fr * L::FRB + 1024) = bl;
-        };
-        float y[9], dist = 0.f;
-        if constexpr (W <= 1) {  // harmonics of this lane's edge (feature-first operands; wave 1 publishes them)
-          const float4* pp = reinterpret_cast<const float4*>(smem + L::o_pos + (s & 1) * 512);
-          const float4 ps = pp[j], pd = pp[16 + j];
-          if constexpr (LMAX == 2) edge_sh(ps, pd, y, dist); else edge_sh1(ps, pd, y, dist);
+        unsigned char* b1 = smem + L::o_b1 + (16 * gg + row) * 16 + 8 * pc;
+        // all reads first: positions, then the three pieces
+        const float4* pp = reinterpret_cast<const float4*>(smem + L::o_pos + (s & 1) * 512);
+        const float4 ps = pp[row], pd = pp[16 + row];
+        float q2[20], q1[12], q0[4];
+        {
+          const f32x4* a2 = reinterpret_cast<const f32x4*>(gimg + row * L::GA_STRIDE + 3 * H * 4 + (16 * pc + 4 * gg) * 5 * 4);
+          const f32x4* a1 = reinterpret_cast<const f32x4*>(gimg + row * L::GA_STRIDE + (16 * pc + 4 * gg) * 3 * 4);
+          const f32x4* a0 = reinterpret_cast<const f32x4*>(gimg + L::GA_BYTES + row * L::GB_ROW + (16 * pc + 4 * gg) * 4);
+#pragma unroll
+          for (int u = 0; u < 5; ++u) { const f32x4 v = a2[u]; q2[4 * u] = v[0]; q2[4 * u + 1] = v[1]; q2[4 * u + 2] = v[2]; q2[4 * u + 3] = v[3]; }
+#pragma unroll
+          for (int u = 0; u < 3; ++u) { const f32x4 v = a1[u]; q1[4 * u] = v[0]; q1[4 * u + 1] = v[1]; q1[4 * u + 2] = v[2]; q1[4 * u + 3] = v[3]; }
+          { const f32x4 v = a0[0]; q0[0] = v[0]; q0[1] = v[1]; q0[2] = v[2]; q0[3] = v[3]; }
         }
-        auto load_deg = [&](auto ltag, auto& x) {  // x[8][D1]: channel 4 p + r of this lane's k slots, scaled
-          constexpr int L1 = decltype(ltag)::value, D1 = 2 * L1 + 1;
-          // first element of degree L1 in this lane's staged row: region B holds 0e, region A [1o | 2e]
-          const unsigned char* xrow = L1 == 0 ? gimg + L::GA_BYTES + j * L::GB_ROW
-                                              : gimg + j * L::GA_STRIDE + (L1 == 1 ? 0 : 3 * H) * ES;
-#pragma unroll
-          for (int p = 0; p < 2; ++p) read_piece<D1, IO16>(xrow + (16 * p + 4 * g) * D1 * ES, p, xs, x);
+        __builtin_amdgcn_sched_barrier(0);
+        float y[9], dist;
+        if constexpr (LMAX == 2) edge_sh(ps, pd, y, dist); else edge_sh1(ps, pd, y, dist);
+        auto put4 = [&](const int fr, const float (&f)[4]) {
+          uint32_t h0, l0, h1, l1;
+          split2_f16(f[0], f[1], h0, l0);
+          split2_f16(f[2], f[3], h1, l1);
+          *reinterpret_cast<uint2*>(b1 + fr * L::FRB) = uint2{h0, h1};
+          *reinterpret_cast<uint2*>(b1 + fr * L::FRB + 1024) = uint2{l0, l1};
         };
-        auto comps = [&](auto ltag, auto& x, const int a0, const int a1) {
-          constexpr int L1 = decltype(ltag)::value;
+        auto degree = [&](auto ltag, float* q) {  // q[r * D1 + a]: channel r of the piece, component a
+          constexpr int L1 = decltype(ltag)::value, D1 = 2 * L1 + 1;
 #pragma unroll
-          for (int a = 0; a < 2 * L1 + 1; ++a)
-            if (a >= a0 && a < a1) {
-              float f[8];
+          for (int i = 0; i < 4 * D1; ++i) q[i] *= xs;   // the operand scale, once
 #pragma unroll
-              for (int i = 0; i < 8; ++i) f[i] = x[i][a];
-              put(L::frag(L1, a), f);
+          for (int a = 0; a < D1; ++a) {
+            const float f[4] = {q[a], q[D1 + a], q[2 * D1 + a], q[3 * D1 + a]};
+            put4(L::frag(L1, a), f);
+          }
+          if constexpr (L1 > 0) {  // feature-first operand f[k] = sum_a z[a] x[k][a]
+            float zz[D1][1];
+            make_z<L1, L1, 0>(y, zz);
+            float f[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float sum = zz[0][0] * q[r * D1];
+#pragma unroll
+              for (int a = 1; a < D1; ++a) sum = __builtin_fmaf(zz[a][0], q[r * D1 + a], sum);
+              f[r] = sum;
             }
+            put4(L::frag_ff(L1), f);
+          }
         };
-        auto ffop = [&](auto ltag, auto& x) {  // f[k] = sum_a z[a] x[k][a]
-          constexpr int L1 = decltype(ltag)::value, D1 = 2 * L1 + 1;
-          float zz[D1][1];
-          make_z<L1, L1, 0>(y, zz);
-          float f[8];
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            float sum = zz[0][0] * x[i][0];
-#pragma unroll
-            for (int a = 1; a < D1; ++a) sum = __builtin_fmaf(zz[a][0], x[i][a], sum);
-            f[i] = sum;
-          }
-          put(L::frag_ff(L1), f);
-        };
-        if constexpr (W == 0) {
-          float x[8][5];
-          load_deg(I2{}, x);
-          comps(I2{}, x, 0, 5);
-          ffop(I2{}, x);
-        } else if constexpr (W == 1) {
-          {
-            float x[8][3];
-            load_deg(I1{}, x);
-            comps(I1{}, x, 0, 3);
-            ffop(I1{}, x);
-          }
-          {
-            float x[8][1];
-            load_deg(I0{}, x);
-            comps(I0{}, x, 0, 1);
-          }
-          if (lane < 16) {
-            f32x4* yp = reinterpret_cast<f32x4*>(smem + L::o_y + (s & 3) * 768 + lane * 48);
-            yp[0] = f32x4{y[0], y[1], y[2], y[3]};
-            yp[1] = f32x4{y[4], y[5], y[6], y[7]};
-            yp[2] = f32x4{y[8], dist, 0.f, 0.f};
-          }
-        }
+        static_assert(!IO16, "fp32 image");
+        degree(I2{}, q2);
+        degree(I1{}, q1);
+        degree(I0{}, q0);
       }
-      // this wave's part of the image has been read (the reads have returned: their values were converted above, and the
-      // wait below covers a tile that was skipped): re-fill it for tile s + 1
-      if constexpr (W <= 1) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (ids_requested(s + 1)) gather_part(s + 1, W);
+      // ---- wave 2: the edge table of tile s (harmonics, distance, dense couplings); waves 0-2: the initial values of the
+      //      scalar-type tiles of product #1 (two tiles each): pre-mix of (0, 0, 0) + d-term + the pre-mix of the feature-first paths folded with their
+      //      couplings -- all of it used to be recomputed / folded by the four product waves ----
+      if (W <= 2 && t0.n > 0) {
+        const float4* pp = reinterpret_cast<const float4*>(smem + L::o_pos + (s & 1) * 512);
+        const float4 ps = pp[j], pd = pp[16 + j];
+        const int slot = (j >= t0.n0 && j < t0.n) ? t0.sl1 : t0.sl0;
+        const float* urow = reinterpret_cast<const float*>(smem + L::o_u + slot * L::U_ROW) + 4 * g;
+        constexpr int T0 = G::T(0);
+        float y[9], dist;
+        if constexpr (LMAX == 2) edge_sh(ps, pd, y, dist); else edge_sh1(ps, pd, y, dist);
+        const float dsc = dist * xs;
+        float z110[3][1], z220[5][1];
+        make_z<1, 1, 0>(y, z110);
+        make_z<2, 2, 0>(y, z220);
+        f32x4* ip = reinterpret_cast<f32x4*>(smem + L::o_init) + lane;
+        // two tiles at a time: their 20 pre-mix reads first (this wave also holds its product weights: all T(0) tiles at
+        // once would need 240 registers), then the folds
+        static_assert(T0 == 6, "two scalar-type tiles per wave 0, 1, 2");
+#pragma unroll
+        for (int t2 = 2 * W; t2 < 2 * W + 2; t2 += 2) {
+          f32x4 u0[2], u1[3][2], u2[5][2], wv[2];
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const int tt = t2 + k;
+            u0[k] = *reinterpret_cast<const f32x4*>(urow + G::uoff(0, 0, 0) + tt * 16);
+            wv[k] = *reinterpret_cast<const f32x4*>(wdtab + 4 * g + G::wdoff(0) + tt * 16);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) u1[a][k] = *reinterpret_cast<const f32x4*>(urow + G::uoff(1, 1, 0) + (a * T0 + tt) * 16);
+#pragma unroll
+            for (int a = 0; a < 5; ++a) u2[a][k] = *reinterpret_cast<const f32x4*>(urow + G::uoff(2, 2, 0) + (a * T0 + tt) * 16);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            f32x4 v = u0[k];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              v[r] = __builtin_fmaf(wv[k][r], dsc, v[r]);
+#pragma unroll
+              for (int a = 0; a < 3; ++a) v[r] = __builtin_fmaf(u1[a][k][r], z110[a][0], v[r]);
+#pragma unroll
+              for (int a = 0; a < 5; ++a) v[r] = __builtin_fmaf(u2[a][k][r], z220[a][0], v[r]);
+            }
+            ip[64 * (t2 + k)] = v;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        // (wave 2) the table row of edge j: lane group 0 writes the harmonics, group k the k-th dense coupling
+        if constexpr (W == 2) {
+        float* zr = reinterpret_cast<float*>(smem + L::o_zt + (s & 1) * 16 * L::ZT * 4) + j * L::ZT;
+        auto store_dense = [&](auto atag, auto btag, auto ctag, float* dstp) {
+          constexpr int A1 = decltype(atag)::value, B1 = decltype(btag)::value, C1 = decltype(ctag)::value;
+          constexpr int Da = 2 * A1 + 1, Dc = 2 * C1 + 1, NE = Da * Dc;
+          float zz[Da][Dc];
+          make_z<A1, B1, C1>(y, zz);
+          float flat[(NE + 3) / 4 * 4];
+#pragma unroll
+          for (int i = 0; i < (NE + 3) / 4 * 4; ++i) flat[i] = i < NE ? zz[i / Dc][i % Dc] : 0.f;
+#pragma unroll
+          for (int q = 0; q < (NE + 3) / 4; ++q)
+            *reinterpret_cast<f32x4*>(dstp + 4 * q) = f32x4{flat[4 * q], flat[4 * q + 1], flat[4 * q + 2], flat[4 * q + 3]};
+        };
+        if (g == 0) {
+          *reinterpret_cast<f32x4*>(zr + L::z_y) = f32x4{y[0], y[1], y[2], y[3]};
+          *reinterpret_cast<f32x4*>(zr + L::z_y + 4) = f32x4{y[4], y[5], y[6], y[7]};
+          *reinterpret_cast<f32x4*>(zr + L::z_y + 8) = f32x4{y[8], dsc, 0.f, 0.f};
+          store_dense(I1{}, I1{}, I2{}, zr + L::z_112);
+        } else if (g == 1) {
+          store_dense(I1{}, I2{}, I1{}, zr + L::z_121);
+        } else if (g == 2) {
+          store_dense(I2{}, I1{}, I1{}, zr + L::z_211);
+        } else {
+          store_dense(I2{}, I2{}, I2{}, zr + L::z_222);
+        }
+        }
       }
     } else {
-      // ---- team 1: product #2 + gate #2 of tile s - 2 -> out tile [row j][output column] ----
-      if (t2.n > 0) {
-        float y[9], dist;
-        load_y(s - 2, y, dist);
-        const float isrow = 1.0f / row_scale(s - 2);
+      // ---- team 1: product #2 + gate #2 of tile s - 1 -> out tile [row j][output column] ----
+      if (t1.n > 0) {
+        float y[10];
+        const float* ztr = reinterpret_cast<const float*>(smem + L::o_zt + ((s - 1) & 1) * 16 * L::ZT * 4) + j * L::ZT;
+        // 1 / (row scale): the scale is a power of two, its inverse is an exponent flip
+        const uint32_t sb = reinterpret_cast<const uint32_t*>(smem + L::o_srow)[((s - 1) & 1) * 16 + j];
+        const float isrow = IO16 ? 1.0f : __builtin_bit_cast(float, 0x7F000000u - sb);
         f32x4 accV[5], accG, accS;
-        ws_tp<LMAX, TT, ROLE, false, IO16>(w, smem + L::o_b2 + lane * 16, y, nullptr, nullptr, 0.f, accV, accG, accS);
+        // (the product wave is the longest of its SIMD pair in either phase: it gets the vector issue slots first)
+        __builtin_amdgcn_s_setprio(WS_PRIO);
+        ws_tp<LMAX, TT, ROLE, false, IO16>(w, smem + L::o_b2 + lane * 16, ztr, nullptr, nullptr, nullptr, accV, accG, accS, y, tpmk);
         const f32x4* nt = reinterpret_cast<const f32x4*>(n2tab) + g;
         float* orow = reinterpret_cast<float*>(smem + L::o_o) + j * L::RS;
         if constexpr (O::tS >= 0) {
@@ -703,146 +783,136 @@ __device__ __forceinline__ void ws_run(const WsArgs& A, unsigned char* smem) {
         }
       }
     }
+    if constexpr (TEAM1) __builtin_amdgcn_s_setprio(0);
     WS_STAMP(0)
     ws_barrier();
     WS_STAMP(1)
     // =========================================== phase Y ===========================================
-    const TileInfo tn = tinfo(s + 1);  // published in phase X
     if constexpr (!TEAM1) {
-      // ---- team 0: product #1 + gate #1 of tile s -> gated messages in accumulator layout = B layout of product #2 ----
+      // ---- team 0: product #1 + gate #1 of tile s; the gated messages leave as the B fragments of product #2 ----
       if (t0.n > 0) {
-        float y[9], dist;
-        load_y(s, y, dist);
+        float y[10];
+        const float* ztr = reinterpret_cast<const float*>(smem + L::o_zt + (s & 1) * 16 * L::ZT * 4) + j * L::ZT;
+        const float* hm = reinterpret_cast<const float*>(smem + L::o_hmx + (s & 1) * 128);
+        const float hs = hm[j], hd = hm[16 + j];
         const int slot = (j >= t0.n0 && j < t0.n) ? t0.sl1 : t0.sl0;
         const float* urow = reinterpret_cast<const float*>(smem + L::o_u + slot * L::U_ROW) + 4 * g;
         f32x4 accV[5], accG, accS;
-        ws_tp<LMAX, TT, ROLE, true, IO16>(w, smem + L::o_b1 + lane * 16, y, urow, wdtab + 4 * g, dist * xs, accV, accG, accS);
+        __builtin_amdgcn_s_setprio(WS_PRIO);
+        ws_tp<LMAX, TT, ROLE, true, IO16>(w, smem + L::o_b1 + lane * 16, ztr, urow, wdtab + 4 * g,
+                                          reinterpret_cast<const f32x4*>(smem + L::o_init) + lane, accV, accG, accS, y, tpmk);
+        const float dsc = y[9];
+        // row scale of the fp16 split: bound of the row's messages -> [2^12, 2^13)  (identical in the four waves: it depends
+        // on the row's inputs only)
+        float srow = 1.0f;
+        if constexpr (!IO16) srow = pow2_scale_from_bits(__builtin_bit_cast(uint32_t, bwx * fmaxf(fmaxf(hs, hd), dsc)), 12);
         const f32x4* nt = reinterpret_cast<const f32x4*>(n1tab) + g;  // norm slot s at nt[4 s]; carries 1 / (sw1 xs)
-        f32x4* mp = reinterpret_cast<f32x4*>(smem + L::o_m + (s & 1) * L::NM * 1024) + lane;
-        float amax = 0.f;
+        // this wave's half (tile t: k slots 4 t .. 4 t + 3) of every fragment lane: 8 bytes hi, 8 bytes lo
+        unsigned char* b2 = smem + L::o_b2 + lane * 16 + 8 * O::t;
+        auto put4 = [&](const int fr, const float (&f)[4]) {
+          uint32_t h0, l0, h1, l1;
+          split2_f16(f[0], f[1], h0, l0);
+          split2_f16(f[2], f[3], h1, l1);
+          *reinterpret_cast<uint2*>(b2 + fr * L::FRB) = uint2{h0, h1};
+          *reinterpret_cast<uint2*>(b2 + fr * L::FRB + 1024) = uint2{l0, l1};
+        };
+        static_assert(!IO16, "fp32 fragments");
         if constexpr (O::tS >= 0) {
           const f32x4 nv = nt[4 * O::tS];
-          f32x4 o;
+          float f[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float sv = accS[r] * nv[r];
-            o[r] = sv * sigmoid_(sv);
-            amax = fmaxf(amax, fabsf(o[r]));
+            f[r] = sv * sigmoid_(sv) * srow;
           }
-          mp[64 * L::mslot(0, O::t, 0)] = o;
+          put4(L::frag(0, 0), f);
         }
         if constexpr (O::LV > 0) {
           constexpr int Dc = 2 * O::LV + 1;
           const f32x4 gn = nt[4 * O::tG];
           float gt[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) gt[r] = sigmoid_(accG[r] * gn[r]);
+          for (int r = 0; r < 4; ++r) gt[r] = sigmoid_(accG[r] * gn[r]) * srow;
+          float y9[9];
+#pragma unroll
+          for (int i = 0; i < 9; ++i) y9[i] = y[i];
+          float zz[Dc][1];
+          make_z<O::LV, O::LV, 0>(y9, zz);
+          float fs[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int c = 0; c < Dc; ++c) {
             const f32x4 nv = nt[4 * (G::slot0(O::LV) + Dc * O::t + c)];
-            f32x4 o;
+            float f[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              o[r] = accV[c][r] * nv[r] * gt[r];
-              amax = fmaxf(amax, fabsf(o[r]));
+              f[r] = accV[c][r] * nv[r] * gt[r];
+              fs[r] = c == 0 ? zz[0][0] * f[r] : __builtin_fmaf(zz[c][0], f[r], fs[r]);
             }
-            mp[64 * L::mslot(O::LV, O::t, c)] = o;
+            put4(L::frag(O::LV, c), f);
           }
+          put4(L::frag_ff(O::LV), fs);  // feature-first operand of product #2: f[k] = sum_c z[c] m[k][c]
         }
-        if constexpr (!IO16) {  // row maximum of this role's part (joined by the readers)
-          amax = fmaxf(amax, __shfl_xor(amax, 16));
-          amax = fmaxf(amax, __shfl_xor(amax, 32));
-          if (lane < 16) reinterpret_cast<float*>(smem + L::o_pmax)[(s & 1) * 64 + ROLE * 16 + lane] = amax;
+        if constexpr (ROLE == 3 && !IO16) {
+          if (lane < 16) reinterpret_cast<float*>(smem + L::o_srow)[(s & 1) * 16 + lane] = srow;
         }
       }
-      if constexpr (W != 2) ws_wait_vm0();  // the copies of phase X have landed before the barrier that publishes them
-    } else {
-      // ---- team 1: gated messages of tile s - 1 -> B fragments of product #2 ----
+      if constexpr (W == 3) ws_wait_vm0();  // the copies of phase X have landed before the barrier that publishes them
+    } else if constexpr (ROLE < 2) {
+      // ---- waves 4 / 5: run sums of tile s - 1 (out tile rows -> at most two runs per column) ----
       if (t1.n > 0) {
-        const f32x4* mp = reinterpret_cast<const f32x4*>(smem + L::o_m + ((s - 1) & 1) * L::NM * 1024) + lane;
-        unsigned char* b2 = smem + L::o_b2 + lane * 16;
-        const float srow = row_scale(s - 1);
-        auto put = [&](const int fr, const float (&f)[8]) {
-          uint4 bh, bl;
-          split8<IO16>(f, bh, bl);
-          *reinterpret_cast<uint4*>(b2 + fr * L::FRB) = bh;
-          if constexpr (!IO16) *reinterpret_cast<uint4*>(b2 + fr * L::FRB + 1024) = bl;
-        };
-        auto getc = [&](const int l, const int a, float (&f)[8]) {  // k slot jj = 4 t + r  <-  slot (l, t, a), element r
-#pragma unroll
-          for (int tt = 0; tt < TT; ++tt) {
-            const f32x4 v = mp[64 * L::mslot(l, tt, a)];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) f[4 * tt + r] = v[r] * srow;
-          }
-        };
-        float y[9], dist;
-        if constexpr (ROLE == 1 || ROLE == 2) load_y(s - 1, y, dist);
-        auto conv = [&](auto ltag, const int a0, const int a1, const bool ff) {
-          constexpr int L1 = decltype(ltag)::value, D1 = 2 * L1 + 1;
-          float fsum[8];
-          float zz[D1][1];
-          if (ff) make_z<L1, L1, 0>(y, zz);
-#pragma unroll
-          for (int a = 0; a < D1; ++a) {
-            if (!(ff || (a >= a0 && a < a1))) continue;
-            float f[8];
-            getc(L1, a, f);
-            if (a >= a0 && a < a1) put(L::frag(L1, a), f);
-            if (ff) {
-#pragma unroll
-              for (int i = 0; i < 8; ++i) fsum[i] = a == 0 ? zz[0][0] * f[i] : __builtin_fmaf(zz[a][0], f[i], fsum[i]);
-            }
-          }
-          if (ff) put(L::frag_ff(L1), fsum);
-        };
-        if constexpr (ROLE == 0) conv(I2{}, 0, 3, false);
-        else if constexpr (ROLE == 1) conv(I2{}, 3, 5, true);
-        else if constexpr (ROLE == 2) conv(I1{}, 0, 3, true);
-        else conv(I0{}, 0, 1, false);
-      }
-      // ---- run sums of tile s - 2 (out tile rows -> at most two runs per column) ----
-      if (t2.n > 0) {
         const float* op = reinterpret_cast<const float*>(smem + L::o_o) + lane;
         float s0[NQW], s1[NQW];
 #pragma unroll
         for (int q = 0; q < NQW; ++q) { s0[q] = 0.f; s1[q] = 0.f; }
-        if (t2.n0 == 16) {  // one run, full tile: the common case
+        float v[16][NQW];
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+          for (int q = 0; q < Q1 - Q0; ++q) v[r][q] = (64 * (Q0 + q) + lane < D) ? op[r * L::RS + 64 * (Q0 + q)] : 0.f;
+        __builtin_amdgcn_sched_barrier(0);
+        if (t1.n0 == 16) {  // one run, full tile: the common case
 #pragma unroll
           for (int r = 0; r < 16; ++r)
 #pragma unroll
-            for (int q = 0; q < Q1 - Q0; ++q)
-              s0[q] += (64 * (Q0 + q) + lane < D) ? op[r * L::RS + 64 * (Q0 + q)] : 0.f;
+            for (int q = 0; q < Q1 - Q0; ++q) s0[q] += v[r][q];
         } else {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
 #pragma unroll
             for (int q = 0; q < Q1 - Q0; ++q) {
-              const float v = (64 * (Q0 + q) + lane < D) ? op[r * L::RS + 64 * (Q0 + q)] : 0.f;
-              s0[q] += r < t2.n0 ? v : 0.f;
-              s1[q] += (r >= t2.n0 && r < t2.n) ? v : 0.f;
+              s0[q] += r < t1.n0 ? v[r][q] : 0.f;
+              s1[q] += (r >= t1.n0 && r < t1.n) ? v[r][q] : 0.f;
             }
           }
         }
-        if (t2.node0 != cur) { flush(); cur = t2.node0; }
+        if (t1.node0 != cur) { flush(); cur = t1.node0; }
 #pragma unroll
         for (int q = 0; q < NQW; ++q) carry[q] += s0[q];
-        if (t2.node1 >= 0) {
+        if (t1.node1 >= 0) {
           flush();
-          cur = t2.node1;
+          cur = t1.node1;
 #pragma unroll
           for (int q = 0; q < NQW; ++q) carry[q] = s1[q];
         }
       }
+    } else {
+      // ---- waves 6 / 7: copies of the h[src] rows of tile s + 1 (the image is free: phase X has read tile s); they have
+      //      landed before the barrier that ends this phase ----
+      if (ids_requested(s + 1)) gather_part(s + 1, ROLE - 2);
+      ws_wait_vm0();
     }
+    if constexpr (!TEAM1) __builtin_amdgcn_s_setprio(0);
+    const TileInfo tn = tinfo(s + 1);  // published in phase X; read here so that its latency hides behind the barrier wait
     WS_STAMP(2)
     ws_barrier();
-    t2 = t1; t1 = t0; t0 = tn;
+    t1 = t0; t0 = tn;
   }
-  if constexpr (TEAM1) flush();
+  if constexpr (RSW) flush();
 #if E3_WS_STAMP
-  if (lane == 0)
+  if (lane == 0) {
     for (int i = 0; i < 4; ++i) atomicAdd(&g_ws_stamps[W][i], (unsigned long long)st_acc[i]);
+    for (int i = 0; i < 8; ++i) atomicAdd(&g_ws_tp[W][i], (unsigned long long)tpmk[i]);
+  }
 #endif
 #undef WS_STAMP
 }
@@ -884,7 +954,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 // ------------------------------------------------------------------------------------------------------------------
 bool msg_ws_supported(int lmax, int hidden, int dtype) { return lmax == 2 && hidden == 32 && (dtype == E3_F32); }
 
-int msg_ws_launch(int lmax, int hidden, int dtype, const void* h, int64_t ldh, const float* pos4, const int32_t* src,
+int msg_ws_launch(int lmax, int hidden, int dtype, const void* h, int64_t ldh, int64_t N, const float* pos4, const int32_t* src,
                   const int32_t* dst, int64_t E, const void* packed, const float* in_scale, const float* premix, float* out,
                   int64_t ldo, int chunk_edges, hipStream_t stream) {
   if (!msg_ws_supported(lmax, hidden, dtype)) return E3_ERR_UNSUPPORTED;
@@ -910,8 +980,9 @@ int msg_ws_launch(int lmax, int hidden, int dtype, const void* h, int64_t ldh, c
   const int64_t nchunks = (E + chunk - 1) / chunk;
   int nwg = (int)std::min<int64_t>(cus, nchunks);  // one workgroup of 8 waves per CU
   nwg = std::max(8, (nwg + 7) / 8 * 8);
-  WsArgs a = {h, ldh, reinterpret_cast<const float4*>(pos4), src, dst, E, static_cast<const float*>(packed), premix, in_scale,
-              out, ldo, chunk};
+  const float* hmax = premix + (size_t)N * MsgGeom<2, 2>::UD;  // per-node row maxima behind the table (e3_msg_premix)
+  WsArgs a = {h, ldh, reinterpret_cast<const float4*>(pos4), src, dst, E, static_cast<const float*>(packed), premix, hmax,
+              in_scale, out, ldo, chunk};
   hipLaunchKernelGGL((msg_ws_kernel<2, 2, false>), dim3(nwg), dim3(512), L::total, stream, a);
   E3_HIP_CHECK(hipGetLastError());
   return E3_OK;
@@ -920,11 +991,13 @@ int msg_ws_launch(int lmax, int hidden, int dtype, const void* h, int64_t ldh, c
 }  // namespace e3
 
 #if E3_WS_STAMP
-extern "C" int e3_msg_ws_debug_stamps(unsigned long long* out32, int reset) {
-  if (out32 && hipMemcpyFromSymbol(out32, HIP_SYMBOL(e3::g_ws_stamps), 256) != hipSuccess) return E3_ERR_HIP;
+extern "C" int e3_msg_ws_debug_stamps(unsigned long long* out96, int reset) {  // [8][4] phases, then [8][8] TP marks
+  if (out96 && hipMemcpyFromSymbol(out96, HIP_SYMBOL(e3::g_ws_stamps), 256) != hipSuccess) return E3_ERR_HIP;
+  if (out96 && hipMemcpyFromSymbol(out96 + 32, HIP_SYMBOL(e3::g_ws_tp), 512) != hipSuccess) return E3_ERR_HIP;
   if (reset) {
-    unsigned long long z[32] = {0};
+    unsigned long long z[64] = {0};
     if (hipMemcpyToSymbol(HIP_SYMBOL(e3::g_ws_stamps), z, 256) != hipSuccess) return E3_ERR_HIP;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(e3::g_ws_tp), z, 512) != hipSuccess) return E3_ERR_HIP;
   }
   return E3_OK;
 }

@@ -55,7 +55,7 @@ for tpb in [int(v) for v in os.environ.get("TPB", "0").split(",")]:
     if os.environ.get("WS_STAMPS"):  # per-wave cycle counters of a -DE3_WS_STAMP=1 build of e3_msg_ws.hip (development)
         import ctypes
         lib = ctypes.CDLL(_L.LIB_PATH)
-        buf = (ctypes.c_ulonglong * 32)()
+        buf = (ctypes.c_ulonglong * 96)()
         lib.e3_msg_ws_debug_stamps(buf, 1)
         layer._msg.forward(h, g, layer.msg1, layer.msg2, sc, edges=edges); torch.cuda.synchronize()
         lib.e3_msg_ws_debug_stamps(buf, 0)
@@ -65,6 +65,10 @@ for tpb in [int(v) for v in os.environ.get("TPB", "0").split(",")]:
         for w in range(8):
             v = [buf[4 * w + i] / nwg / steps for i in range(4)]
             print(f"   wave {w}: {v[0]:8.0f} {v[1]:8.0f} {v[2]:8.0f} {v[3]:8.0f}   sum {sum(v):8.0f}")
+        print("   tensor product marks, cycles per tile: [first requests | degree 2 | degree 1 (+fold 2) | degree 0 (+fold 1) | fold 0]  (rest of the phase = gate + stores)")
+        for w in range(8):
+            v = [buf[32 + 8 * w + i] / nwg / steps for i in range(5)]
+            print(f"   wave {w}: " + " ".join(f"{x:7.0f}" for x in v) + f"   sum {sum(v):7.0f}")
     fl = layer._msg.flops_per_edge() * E
     print(f"[{os.environ.get('E3_EXP_LIB','default')}] N={N} E={E} lmax={lmax} H={H} tpb={tpb} zero_idx={bool(edges)}: {ms:.2f} ms/launch pair  {E/ms/1e3:.0f} Medges/s  "
           f"{fl/ms/1e9:.1f} TFLOP/s algorithmic ({3*fl/ms/1e9/2500*100:.1f} % of bf16/f16 MFMA peak executed x3)")
