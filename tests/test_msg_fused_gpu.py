@@ -57,9 +57,9 @@ def test_fused_message_matches_unfused_chain(lmax, H, N, k):
 
 def test_fused_message_feature_scales():
     """Tiny and large features: the per-tensor (h) and per-edge-row (messages) power-of-two scales keep fp32 accuracy.
-    (Beyond |h| ~ 1e2 the comparison itself is ill-conditioned in fp32: the gates' sigmoid amplifies the absolute rounding
-    error ~ eps |h| of its argument, for ANY fp32 implementation -- measured 1.7e-6 at 1e2, 6e-5 at 1e3 for the fused
-    kernel and 2.7e-6 / 5e-5 for the per-TP kernels against the same FMA chain.)"""
+    (Beyond |h| ~ 1e2 the comparison against the exact-fp32 chain is itself ill-conditioned: the gates' sigmoid amplifies the
+    absolute rounding error ~ eps |h| of its argument for ANY fp32 implementation.  test_exact_chain_vs_fp64_at_large_feature_scales
+    measures both against fp64: exact chain 1.7e-6 / 5.0e-5, fused kernel 1.1e-6 / 2.9e-5 at |h| = 1e2 / 1e3.)"""
     torch.manual_seed(5)
     g, _ = _graph(900, 12.0, seed=4)
     layer = SEGNNLayer(32, 2).to(DEV)
@@ -115,6 +115,75 @@ def test_fused_message_edge_subsets():
                 touched = torch.zeros(N, dtype=torch.bool, device=DEV)
                 touched[dst.long()] = True
                 assert float(got[~touched].abs().max()) == 0.0, name   # rows without a selected edge stay exactly zero
+
+
+def test_fused_message_mixed_row_magnitudes():
+    """Rows of very different magnitude in ONE tensor (node scales 1e-2 .. 1e2).  The weights-stationary kernel scales the
+    fp16 (hi, lo) operands of product #2 per edge row from a BOUND (weights x row maxima of h[src], h[dst], d) instead of the
+    row's measured maximum: the bound must never be exceeded (no inf / nan) and a loose bound must not cost accuracy."""
+    torch.manual_seed(21)
+    g, _ = _graph(1200, 14.0, seed=6)
+    layer = SEGNNLayer(32, 2).to(DEV)
+    Y, d, A = ops.edge_geometry(g, lmax=2)
+    scale = torch.tensor([1e-2, 1.0, 1e2], device=DEV)[torch.randint(0, 3, (1200,), device=DEV)]
+    h = torch.randn(1200, 288, device=DEV) * scale[:, None]
+    with torch.no_grad():
+        want = _unfused(layer, h, g, Y, d)
+        for tpb in (0, -4):
+            layer._msg.tiles_per_block = tpb
+            got = layer._msg.forward(h, g, layer.msg1, layer.msg2)
+            assert torch.isfinite(got).all()
+            err = float((got - want).abs().max() / want.abs().max())
+            assert err < 3e-6, (tpb, err)
+            # nodes whose whole neighbourhood is small: accuracy relative to THEIR OWN scale (the operand scale of h is one
+            # power of two per tensor, so rows 1e4 below the tensor maximum keep ~1e-3 of relative accuracy; 1e-2 nodes ~1e-5)
+            small = (scale == 1e-2)
+            if small.any():
+                rel = float((got[small] - want[small]).abs().max() / want[small].abs().max())
+                assert rel < 1e-3, (tpb, rel)
+
+
+def test_exact_chain_vs_fp64_at_large_feature_scales():
+    """is the comparison "fused kernel vs exact-fp32 chain" itself ill-conditioned beyond |h| ~ 1e2?
+    One message function at |h| in {1, 1e2, 1e3}: the exact-fp32 FMA chain and the fused (split-MFMA) kernel, both against the
+    fp64 oracle of the same function.  The figures are printed; the fused kernel must be as close to fp64 as the exact chain
+    within a factor of 4 (it is the fp32 chain that loses accuracy there, through the sigmoid of O(|h|) arguments)."""
+    from oracle import segnn_oracle as S
+    torch.manual_seed(5)
+    g, pos = _graph(900, 12.0, seed=4)
+    layer = SEGNNLayer(32, 2).to(DEV)
+    Y, d, A = ops.edge_geometry(g, lmax=2)
+    layer64 = SEGNNLayer(32, 2).to(DEV).double()
+    layer64.load_state_dict({k: v.double() for k, v in layer.state_dict().items()})
+    for tp in (layer64.msg1, layer64.msg2):
+        tp.exact = True
+    H, dst, src = 32, g.dst.long(), g.src.long()
+
+    def gate64(t):  # [H scalars | H gates of 1o | H gates of 2e | H x 1o | H x 2e]
+        sc_, g1, g2 = t[:, :H], t[:, H:2 * H], t[:, 2 * H:3 * H]
+        v1, v2 = t[:, 3 * H:6 * H].reshape(-1, H, 3), t[:, 6 * H:].reshape(-1, H, 5)
+        return torch.cat([torch.nn.functional.silu(sc_), (torch.sigmoid(g1)[:, :, None] * v1).reshape(-1, 3 * H),
+                          (torch.sigmoid(g2)[:, :, None] * v2).reshape(-1, 5 * H)], 1)
+
+    def chain64(h64):  # fp64: torch gather / gate / index_add around the fp64 generic tensor-product kernel
+        m = torch.cat([h64[dst], h64[src], d.double()[:, None]], 1)
+        m = gate64(layer64.msg1(m, Y.double()))
+        m = gate64(layer64.msg2(m, Y.double()))
+        return torch.zeros(900, 288, device=DEV, dtype=torch.float64).index_add_(0, dst, m)
+
+    lines = []
+    for sc in (1.0, 1e2, 1e3):
+        h = torch.randn(900, 288, device=DEV) * sc
+        with torch.no_grad():
+            want = chain64(h.double())
+            exact = _unfused(layer, h, g, Y, d).double()                        # exact fp32 FMA chain
+            layer._msg.tiles_per_block = 0
+            fused = layer._msg.forward(h, g, layer.msg1, layer.msg2).double()
+        e_exact = float((exact - want).abs().max() / want.abs().max())
+        e_fused = float((fused - want).abs().max() / want.abs().max())
+        lines.append(f"|h| ~ {sc:g}: exact fp32 chain vs fp64 {e_exact:.2e} | fused split-MFMA kernel vs fp64 {e_fused:.2e}")
+        assert e_fused <= max(4 * e_exact, 3e-6), (sc, e_exact, e_fused)
+    print("\n" + "\n".join(lines))
 
 
 def test_fused_message_empty_graph():

@@ -56,6 +56,30 @@ def test_four_layers_bench_mode_meets_1e5(lmax):
     assert e_exact <= 1e-5, e_exact
 
 
+# bound of the bf16-storage leg (BASELINE.json configs[2]) after 4 layers, relative to the output scale; the measured figure
+# is printed by the test and quoted in bench.py's `bf16_storage.numerics`
+BF16_FOUR_LAYER_BOUND = 2e-2   # measured 6.8e-3 (round 3)
+
+
+def test_four_layers_bf16_storage_record():
+    """configs[2] at the configured depth: the 4-layer H=32 l_max=2 model in bf16 storage (bf16 features / weights / norms /
+    messages, fp32 harmonics, accumulators and sums) against the fp64 oracle evaluated on the bf16-rounded inputs and
+    parameters -- i.e. the error of the bf16 ARITHMETIC path, not of rounding the model."""
+    model, g, xs, args, geo = _case(2000, 32, 4, 2, seed=5)
+    m16 = SEGNN("1x0e+1x1o", 32, "1x1o", 4, lmax=2).to(DEV)
+    m16.load_state_dict(model.state_dict())
+    m16 = m16.bfloat16()
+    params16 = {k: v.detach().float().double().cpu().numpy() for k, v in m16.state_dict().items()}  # exactly the bf16 values
+    x16 = xs.bfloat16()
+    want = S.forward_l2(params16, *args[1:], x16.double().numpy(), *geo)
+    with torch.no_grad():
+        got = m16(x16.to(DEV), g).double().cpu().numpy()
+    err = _rel(got, want)
+    print(f"\n4-layer l_max=2 H=32 N=2000 bf16 storage vs fp64 oracle on the bf16-rounded model: {err:.2e}")
+    assert np.isfinite(got).all()
+    assert err <= BF16_FOUR_LAYER_BOUND, err
+
+
 def test_modes_separate_segment_sum_is_reproducible():
     """fuse_scatter = False: message TP #2 writes its rows, e3_segment_sum adds them in a fixed order."""
     model, g, xs, args, geo = _case(600, 32, 1, 2, seed=8)
