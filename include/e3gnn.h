@@ -174,6 +174,18 @@ int e3_gate(const float* in, int64_t ld_in, float* out, int64_t ld_out, int64_t 
 int e3_segment_sum(const float* msg, int64_t ld_msg, const int32_t* rowptr, int64_t N, int D,
                    float* agg, int64_t ld_agg, void* stream);
 
+/* Sharded graph (sharding.GridHalo.split_graph): from the CSR graph of the local cloud (owned + ghost rows) and the per-row
+ * ghost flags (uint8), drop the edges INTO ghost rows and split the rest by the ownership of their src -- classification and
+ * compaction in one call, every output sorted by dst:
+ *   rowptr_kept [N+1], (src_kept, dst_kept) [E_kept]: the graph without the dropped rows' edges
+ *   (src_interior, dst_interior): kept edges with an owned src;  (src_boundary, dst_boundary): kept edges with a ghost src
+ *   counts[0..2] = E_kept, E_interior, E_boundary (device memory; the caller reads them once to size its views)
+ * The six edge outputs need room for E elements each; workspace = e3_split_edges_workspace_bytes(N) bytes. */
+int64_t e3_split_edges_workspace_bytes(int64_t N);
+int e3_split_edges(const int32_t* rowptr, const int32_t* src, const uint8_t* is_ghost, int64_t N, int64_t E,
+                   int32_t* rowptr_kept, int32_t* src_kept, int32_t* dst_kept, int32_t* src_interior, int32_t* dst_interior,
+                   int32_t* src_boundary, int32_t* dst_boundary, int32_t* counts, void* workspace, void* stream);
+
 /* =================================================================================================
  * General SH tensor product, l <= 2 (builder-defined generalisation of the reference operator, which
  * hard-asserts lmax == 1, l1_tensor_prod.py:13-14).

@@ -48,6 +48,9 @@ SIGNATURES = {
                                  c_int64, c_void_p]),
     "e3_gate": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p]),
     "e3_segment_sum": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p]),
+    "e3_split_edges_workspace_bytes": (c_int64, [c_int64]),
+    "e3_split_edges": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "e3_tp_plan_create": (c_int, [POINTER(c_int32), c_int, c_int, POINTER(c_int32), c_int, POINTER(c_void_p)]),
     "e3_tp_plan_destroy": (c_int, [c_void_p]),
     "e3_tp_in1_dim": (c_int, [c_void_p]),

@@ -102,14 +102,30 @@ class FusedMessage:
                             fl += 2 * n[l1] * M * min(2 * l1 + 1, 2 * l3 + 1)
         return fl
 
+    def refresh_row_max(self, state, h: torch.Tensor, rows: torch.Tensor, in_scale: torch.Tensor | None):
+        """The pre-mix launch leaves max |h[n] in_scale| per node behind its table (the edge kernel bounds a row's messages
+        with it).  After rows of ``h`` were overwritten (halo refresh of the ghost rows) their entries are recomputed here
+        -- device-side, no sync -- and the largest scaled value is returned (device scalar) for the caller's overflow guard."""
+        premix = state[1]
+        N = h.shape[0]
+        ud = premix.numel() // N - 1
+        hmax = premix[N * ud:]
+        m = h[rows].float().abs().amax(1) if rows.numel() else h.new_zeros(0, dtype=torch.float32)
+        if in_scale is not None and h.dtype == torch.float32:
+            m = m * in_scale[0]
+        hmax[rows] = m
+        return m.max() if m.numel() else torch.zeros((), device=h.device)
+
     def forward(self, h: torch.Tensor, g: RadiusGraph, msg1, msg2, in_scale: torch.Tensor | None = None, edges=None,
-                cont=None):
+                cont=None, return_state: bool = False):
         """h [N, width] fp32 | bf16 (Morton order of ``g``) -> aggregated messages [N, width] in h's dtype (the sums are
         fp32 in both cases; bf16 storage rounds them once).
 
         ``edges = (src, dst)``: an explicit dst-sorted edge list instead of ``g``'s (sharding: interior / boundary edges).
-        ``cont``: the ``(out, premix)`` pair a previous call returned through ``return_state`` semantics -- the call then ADDS
-        its edges' messages to ``out`` (same ``h`` rows for every dst node required) and returns ``out``."""
+        ``return_state``: return ``(out, state)`` with ``state = (out, premix)`` -- the pre-mix table (6.8 GB at 1 M
+        particles) stays referenced only as long as the caller keeps it.
+        ``cont``: such a state -- the call then ADDS its edges' messages to ``out`` (same ``h`` rows for every dst node
+        required) and returns ``out``."""
         if not h.is_cuda or not self.supports(h.dtype):
             raise RuntimeError(f"fused message: ROCm tensor in float32 (or bfloat16 for hidden >= 32) required, got "
                                f"{h.dtype} on {h.device} (no CPU path)")
@@ -128,9 +144,8 @@ class FusedMessage:
             out = torch.empty((N, W), dtype=torch.float32, device=dev)
         else:
             out = cont[0]
-        self.last_state = None
         if N == 0:
-            return out.to(io)
+            return (out.to(io), None) if return_state else out.to(io)
         with torch.cuda.device(dev):
             packed = self.packed(msg1, msg2, dev, io)
             if in_scale is None and io == torch.float32:
@@ -162,5 +177,5 @@ class FusedMessage:
                 nb = esz * N * W + 16 * N + 8 * E + 4 * N * W
                 profiling.end(f"msg_fused lmax={self.lmax} H={self.hidden} E={E} {io}", E, nb, t0,
                               flops=self.flops_per_edge() * E, kernel="e3::msg_fused_kernel" + mode)
-        self.last_state = (out, premix)
-        return out  # fp32 sums; callers in bf16 storage round once (SEGNNLayer)
+        # fp32 sums; callers in bf16 storage round once (SEGNNLayer)
+        return (out, (out, premix)) if return_state else out

@@ -74,7 +74,7 @@ class SEGNNLayer(nn.Module):
         return f
 
     def forward(self, h, g: RadiusGraph, Y, d, A, h_scale=None, halo=None, split=None):
-        """-> (h_next, operand scale of h_next | None).  ``halo`` / ``split`` (sharding.SlabHalo / SplitGraph): the layer
+        """-> (h_next, operand scale of h_next | None).  ``halo`` / ``split`` (sharding.GridHalo / SplitGraph): the layer
         refreshes the ghost rows of ``h`` itself -- in place -- and overlaps the transfer with the interior edges."""
         inference = not (torch.is_grad_enabled() and _needs_grad(self, h))
         f32 = h.dtype == torch.float32
@@ -88,15 +88,25 @@ class SEGNNLayer(nn.Module):
             halo.exchange(h)  # blocking refresh of the ghost rows, in place
         if one_launch and halo is not None and split is not None:
             # the refresh is posted first; interior edges (owned src) run while it is in flight, boundary edges after it
-            # landed.  The operand scale comes from the owned + stale ghost rows: one binade of head room covers the
-            # refreshed ghosts (they are rows of the neighbours' h of the same layer; checked in the sharding tests).
+            # landed.  The operand scale has to be fixed BEFORE the refreshed ghost rows are known (the pre-mix table and
+            # the interior launch use it): it is taken from the owned + stale ghost rows with NINE binades of head room
+            # (joint maximum at 2^6 instead of 2^10) -- the fp16 (hi, lo) pair keeps an absolute error of 2^-25 of the scaled
+            # range, so the lower target costs no accuracy, and refreshed rows up to 512 x larger than anything this rank
+            # held stay inside the fp16 range.  Beyond that the overflow flag of the halo is raised (checked once per forward).
             tok = halo.start(h)
             if h_scale is None and f32:
-                h_scale = ops.pow2_scale([h], target_log2=9)
-            a = self._msg.forward(h, split.graph, self.msg1, self.msg2, h_scale, edges=split.interior)
+                h_scale = ops.pow2_scale([h], target_log2=6)
+            a, state = self._msg.forward(h, split.graph, self.msg1, self.msg2, h_scale, edges=split.interior,
+                                         return_state=True)
             halo.finish(h, tok)
-            a = self._msg.forward(h, split.graph, self.msg1, self.msg2, h_scale, edges=split.boundary,
-                                  cont=self._msg.last_state).to(h.dtype)
+            if state is not None:
+                # the pre-mix launch saw the STALE ghost rows: their row maxima (bound of a row's messages) are recomputed
+                top = self._msg.refresh_row_max(state, h, halo.ghost_rows(), h_scale if f32 else None)
+                if f32:
+                    flag = top >= 2.0 ** 15
+                    halo.overflow = flag if getattr(halo, "overflow", None) is None else (halo.overflow | flag)
+            a = self._msg.forward(h, split.graph, self.msg1, self.msg2, h_scale, edges=split.boundary, cont=state).to(h.dtype)
+            del state
         elif one_launch:
             # one launch: SH + TP #1 + gate + TP #2 + gate + segment-sum (message.FusedMessage)
             if h_scale is None and f32:
@@ -170,8 +180,15 @@ class SEGNN(nn.Module):
             raise RuntimeError("bf16 storage is implemented for l_max = 2 (BASELINE config 3)")
         h = self.embed(x, A)
         sc = None
+        if halo is not None:
+            halo.overflow = None
         for layer in self.layers:
             if halo is not None:
                 sc = None  # the ghost rows are about to change: the scale of the previous layer's output is stale
             h, sc = layer(h, g, Y, d, A, sc, halo=halo, split=split)
-        return self.readout(h, A)
+        out = self.readout(h, A)
+        if halo is not None and getattr(halo, "overflow", None) is not None and bool(halo.overflow):
+            raise RuntimeError("sharded forward: a refreshed ghost row is more than 512 x larger than every row this rank held "
+                               "when the layer's operand scale was fixed (fp16-split operands would overflow); run the layer "
+                               "without `split` (blocking exchange) for such inputs")
+        return out

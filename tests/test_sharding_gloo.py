@@ -176,3 +176,98 @@ def test_sharded_forward_world4_empty_rank_and_empty_halos():
     assert halos[2][3] == 0                                  # rank 2 owns nothing
     assert halos[1][0] == 0 or halos[1][1] == 0              # rank 1 has an empty halo on at least one side
     assert halos[3][0] == 0                                  # nothing arrives from the empty slab
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# ONE cloud cut into 2 x 2 x 2 octants (= the top level of the Morton order): the strong-scaling layout; neighbour sets > 2
+# ---------------------------------------------------------------------------------------------------------------------
+def _octant_worker(rank, world, port, N, H, L, out_q):
+    sys.path.insert(0, REPO)
+    import models  # noqa
+    from oracle import graph_oracle as G
+    from oracle import segnn_oracle as S
+    from scalable_e3_gnn_amd.radius_graph import RadiusGraph
+    from scalable_e3_gnn_amd.segnn import SEGNN
+    from scalable_e3_gnn_amd.sharding import GridHalo
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g0 = torch.Generator().manual_seed(11)
+        pos = torch.rand(N, 3, generator=g0, dtype=torch.float64)
+        x = torch.randn(N, 4, generator=g0, dtype=torch.float64)
+        r = float((3 * 10.0 / (4 * np.pi * N)) ** (1 / 3))
+        torch.manual_seed(0)
+        model = SEGNN("1x0e+1x1o", H, "1x1o", L)
+        params = {k: v.detach().double().numpy() for k, v in model.state_dict().items()}
+
+        halo = GridHalo((2, 2, 2), (0, 0, 0), (1, 1, 1))
+        assert len(halo.neighbours) == 7                      # every octant touches the 7 others
+        own = (halo.owner_of(pos) == rank).nonzero().flatten()
+        lpos, lx = halo.setup(pos[own].float().double(), x[own], r)
+        blo, bhi = halo.box(rank)
+        lo, hi = [v - 2 * r for v in blo], [v + 2 * r for v in bhi]
+        nloc = lpos.shape[0]
+        perm, rowptr, src = G.graph(lpos.numpy(), lo, hi, r)
+        halo.renumber(torch.as_tensor(perm))
+        lp, lxx = lpos.numpy().astype(np.float32)[perm], lx.numpy()[perm]
+        g = RadiusGraph(torch.as_tensor(perm), torch.zeros(nloc, 4), torch.as_tensor(rowptr), torch.as_tensor(src),
+                        len(src), ((1, 1, 1), 0))
+        sp = halo.split_graph(g)
+        ghost = halo.is_ghost.numpy()
+        assert not ghost[sp.graph.dst.numpy()].any()
+        assert len(sp.interior[0]) + len(sp.boundary[0]) == sp.graph.num_edges
+
+        def exchange(h):
+            t = torch.as_tensor(h)
+            return halo.finish(t, halo.start(t)).numpy()
+
+        out = S.forward(params, H, L, "1x0e+1x1o", "1x1o", lxx, lp, sp.graph.rowptr.numpy(), sp.graph.src.numpy(),
+                        exchange=exchange)
+        owned_out = out[halo.owned_new.numpy()]
+        # the same cloud cut into 8 slabs along x, for the ghost-fraction comparison only (no forward)
+        slab = GridHalo((8, 1, 1), (0, -1e30, -1e30), (1, 1e30, 1e30))
+        sown = (slab.owner_of(pos) == rank).nonzero().flatten()
+        slab.setup(pos[sown].float().double(), x[sown], r)
+        if rank == 0:
+            gperm, grp, gsrc = G.graph(pos.numpy(), [0, 0, 0], [1, 1, 1], r)
+            want = S.forward(params, H, L, "1x0e+1x1o", "1x1o", x.numpy()[gperm], pos.numpy().astype(np.float32)[gperm], grp, gsrc)
+            full = np.empty_like(want)
+            full[gperm] = want
+            out_q.put(("ref", full, None))
+        out_q.put(("part", owned_out, own.numpy()))
+        out_q.put(("halo", np.array([halo.n_ghost, own.numel(), sum(1 for c in halo.recv_counts if c > 0), slab.n_ghost,
+                                     sown.numel(), sum(1 for c in slab.recv_counts if c > 0), r]), rank))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(420)
+def test_octant_partition_world8_equals_unsharded():
+    """8 ranks, ONE unit cube: sharded forward on octants == unsharded forward; ghost fraction of octants vs 8 x-slabs."""
+    world, N, H, L = 8, 6000, 4, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_octant_worker, args=(r, world, port, N, H, L, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=400) for _ in range(1 + 2 * world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref = [g for g in got if g[0] == "ref"][0][1]
+    merged = np.full_like(ref, np.nan)
+    for tag, val, idx in got:
+        if tag == "part":
+            merged[idx] = val
+    assert not np.isnan(merged).any(), "every particle must be owned by exactly one rank"
+    assert np.abs(merged - ref).max() / np.abs(ref).max() < 1e-10
+    halos = np.stack([val for tag, val, idx in got if tag == "halo"])
+    oct_frac, slab_frac = halos[:, 0].sum() / halos[:, 1].sum(), halos[:, 3].sum() / halos[:, 4].sum()
+    r = halos[0, 6]
+    print(f"\nworld 8, one unit cube, N={N}, r={r:.3f}: octants ghosts/owned = {oct_frac:.3f} over {halos[:, 2].mean():.1f} "
+          f"neighbours per rank; 8 x-slabs ghosts/owned = {slab_frac:.3f} over {halos[:, 5].mean():.1f} neighbours per rank")
+    assert (halos[:, 2] >= 3).all()                           # neighbour sets > 2: faces, edges and the corner
+    assert oct_frac < slab_frac                               # fewer ghosts than slabs of width 1/8, spread over more links

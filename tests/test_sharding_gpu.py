@@ -1,5 +1,7 @@
-"""Two ranks share cuda:0 (gloo transport, host-staged halo) and run the real kernels: the sharded
-SEGNN forward over slabs + ghosts must match the single-process forward over the whole cloud."""
+"""Two ranks share cuda:0 (gloo transport, host-staged halo) and run the real kernels: the sharded SEGNN forward over slabs +
+ghosts must match the single-process forward over the whole cloud and -- for the l_max = 2 cases -- the numpy fp64 oracle of
+the whole cloud.  `boost`: the features of rank 1's particles are multiplied by it, so that the refreshed ghost rows of rank 0
+are far larger than every row rank 0 held when the layer's operand scale was fixed (the stale-ghost scale)."""
 import os
 import socket
 import sys
@@ -13,7 +15,7 @@ pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, N, H, L, lmax, q):
+def _worker(rank, world, port, N, H, L, lmax, boost, q):
     sys.path.insert(0, REPO)
     import torch.distributed as dist
     import models  # noqa
@@ -29,6 +31,7 @@ def _worker(rank, world, port, N, H, L, lmax, q):
         pos = torch.rand(N, 3, generator=g0)
         pos[:, 0] *= world
         x = torch.randn(N, 4, generator=g0)
+        x[pos[:, 0] >= 1.0] *= boost
         r = float((3 * 16.0 / (4 * np.pi * (N / world))) ** (1 / 3))
         torch.manual_seed(0)
         model = SEGNN("1x0e+1x1o", H, "1x1o", L, lmax=lmax).to(dev)
@@ -51,22 +54,31 @@ def _worker(rank, world, port, N, H, L, lmax, q):
             ref = torch.empty_like(full)
             ref[gg.perm.long()] = full
             q.put(("ref", ref.cpu().numpy(), None))
+            if lmax == 2 and N <= 8000:   # an independent reference too: the fp64 oracle of the unsharded cloud
+                from oracle import segnn_oracle as S
+                params = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+                perm = gg.perm.cpu().numpy()
+                want = S.forward_l2(params, H, L, "1x0e+1x1o", "1x1o", x.double().numpy()[perm], pos.numpy()[perm],
+                                    gg.rowptr.cpu().numpy(), gg.src.cpu().numpy())
+                o64 = np.empty_like(want)
+                o64[perm] = want
+                q.put(("oracle", o64, None))
         dist.barrier()
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("H,lmax", [(16, 1), (32, 2)])
-def test_sharded_gpu_forward_equals_single_process(H, lmax):
-    world, N, L = 2, 20000, 3
+@pytest.mark.parametrize("H,lmax,N,boost", [(16, 1, 20000, 1.0), (32, 2, 20000, 1.0), (32, 2, 6000, 1.0), (32, 2, 6000, 100.0)])
+def test_sharded_gpu_forward_equals_single_process(H, lmax, N, boost):
+    world, L = 2, 3
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, N, H, L, lmax, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, N, H, L, lmax, boost, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = [q.get(timeout=240) for _ in range(world + 1)]
+    got = [q.get(timeout=240) for _ in range(world + 1 + (1 if (lmax == 2 and N <= 8000) else 0))]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -77,3 +89,8 @@ def test_sharded_gpu_forward_equals_single_process(H, lmax):
             merged[idx] = val
     assert not np.isnan(merged).any()
     assert np.abs(merged - ref).max() / np.abs(ref).max() < 2e-5   # fp32, different summation order per row
+    for tag, val, _ in got:
+        if tag == "oracle":
+            err = np.abs(merged - val).max() / np.abs(val).max()
+            print(f"\nsharded HIP forward (2 ranks, boost {boost:g}) vs fp64 oracle of the whole cloud: {err:.2e}")
+            assert err < 1e-5, err
