@@ -48,6 +48,8 @@ def _make_tp(in_irreps, out_irreps, lmax: int):
 
 
 class SEGNNLayer(nn.Module):
+    _warned_unfused = False   # the fused -> unfused switch is announced once per process
+
     def __init__(self, H: int, lmax: int = 1):
         super().__init__()
         hid, gated = _hidden_irreps(H, lmax)
@@ -77,6 +79,15 @@ class SEGNNLayer(nn.Module):
         """-> (h_next, operand scale of h_next | None).  ``halo`` / ``split`` (sharding.GridHalo / SplitGraph): the layer
         refreshes the ghost rows of ``h`` itself -- in place -- and overlaps the transfer with the interior edges."""
         inference = not (torch.is_grad_enabled() and _needs_grad(self, h))
+        if not inference and self.fused and not SEGNNLayer._warned_unfused:
+            # the switch is visible: the fused MFMA kernels are inference kernels (no backward); a call that needs a gradient
+            # runs the differentiable chain (gather -> TP -> gate -> TP -> gate -> segment-sum on the generic FMA kernels,
+            # [E, width] tensors in HBM), which is several times slower -- tools/train_step_bench.py measures both
+            SEGNNLayer._warned_unfused = True
+            import warnings
+            warnings.warn("SEGNNLayer: a gradient is required (grad mode on and an input or parameter requires grad) -> the "
+                          "unfused differentiable chain runs instead of the fused MFMA inference kernels; wrap inference in "
+                          "torch.no_grad() to get the fast path", RuntimeWarning, stacklevel=2)
         f32 = h.dtype == torch.float32
         r16 = self.fused and inference and self.fused_available()   # per-TP fused kernels (gather + TP + gate)
         if h.dtype == torch.bfloat16 and not r16:
