@@ -132,6 +132,22 @@ __device__ __forceinline__ void ws_wait_vm0() { asm volatile("s_waitcnt vmcnt(0)
 // workgroup barrier: this wave's LDS writes have completed; no vmcnt wait (copies and atomics stay in flight across it)
 __device__ __forceinline__ void ws_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ int sgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// 4 values = half of a fragment lane (k slots 4 t .. 4 t + 3): fp32 storage: fp16 (hi, lo) halves, 8 bytes each (lo 1 KiB
+// behind hi); bf16 storage: 4 bf16, rounded once
+template <bool IO16>
+__device__ __forceinline__ void ws_put4(unsigned char* dst, const float (&f)[4]) {
+  if constexpr (IO16) {
+    const uint32_t a = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{f[0], f[1]}, bf16x2_t));
+    const uint32_t b = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{f[2], f[3]}, bf16x2_t));
+    *reinterpret_cast<uint2*>(dst) = uint2{a, b};
+  } else {
+    uint32_t h0, l0, h1, l1;
+    split2_f16(f[0], f[1], h0, l0);
+    split2_f16(f[2], f[3], h1, l1);
+    *reinterpret_cast<uint2*>(dst) = uint2{h0, h1};
+    *reinterpret_cast<uint2*>(dst + 1024) = uint2{l0, l1};
+  }
+}
 template <class F>
 __device__ __forceinline__ void sfor3(F&& f) {  // f(integral_constant<int, 0 .. 2>)
   f(std::integral_constant<int, 0>{}); f(std::integral_constant<int, 1>{}); f(std::integral_constant<int, 2>{});
@@ -461,20 +477,24 @@ __device__ __forceinline__ void ws_run(const WsArgs& A, unsigned char* smem) {
   auto gather_part = [&](const int tile, const int part) {
     const int* ids = reinterpret_cast<const int*>(smem + L::o_ids) + (tile & 3) * 32;
     const uint32_t gb = lds0 + L::o_g;
-    static_assert(L::GA_ROW == 1024 && L::GB_ROW == 128, "copy shapes of the fp32 image");
+    static_assert((L::GA_ROW == 1024 && L::GB_ROW == 128) || (L::GA_ROW == 512 && L::GB_ROW == 64), "copy shapes of the image");
+    constexpr int LA = L::GA_ROW / 16;          // lanes of one region-A row copy (64 fp32, 32 bf16)
+    constexpr int UPR = L::GB_ROW / 16;         // 16-byte units per [0e] row (8 / 4)
+    constexpr int RPC = 64 / UPR;               // [0e] rows per copy (8: one piece per part / 16: part 0 copies them all)
     // every LDS read first (the copies are asm statements with a memory clobber: a read between two of them stays there and
     // exposes its latency once per row); row ids reach the scalar unit by v_readlane
     const int myid = ids[lane & 15];
-    const int ridb = ids[8 * part + (lane >> 3)];
+    const int ridb = ids[(RPC == 8 ? 8 * part : 0) + lane / UPR];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const int r = 8 * part + k;
       const int rid = part == 0 ? __builtin_amdgcn_readlane(myid, k) : __builtin_amdgcn_readlane(myid, 8 + k);
       const char* rowp = hb + ((int64_t)rid * A.ldh + H) * ES;
-      dma16(rowp + lane * 16, sgpr((int)(gb + r * L::GA_STRIDE)));
+      if (LA >= 64 || lane < LA) dma16(rowp + lane * 16, sgpr((int)(gb + r * L::GA_STRIDE)));
     }
-    dma16(hb + (int64_t)ridb * A.ldh * ES + (lane & 7) * 16, sgpr((int)(gb + L::GA_BYTES + part * 1024)));
+    if (RPC == 8 || part == 0)
+      dma16(hb + (int64_t)ridb * A.ldh * ES + (lane % UPR) * 16, sgpr((int)(gb + L::GA_BYTES + (RPC == 8 ? part * 1024 : 0))));
   };
   auto ids_requested = [&](const int tile) -> bool {
     return sgpr(reinterpret_cast<const int*>(smem + L::o_idok)[tile & 3]) != 0;
@@ -616,29 +636,37 @@ __device__ __forceinline__ void ws_run(const WsArgs& A, unsigned char* smem) {
         const float4 ps = pp[row], pd = pp[16 + row];
         float q2[20], q1[12], q0[4];
         {
-          const f32x4* a2 = reinterpret_cast<const f32x4*>(gimg + row * L::GA_STRIDE + 3 * H * 4 + (16 * pc + 4 * gg) * 5 * 4);
-          const f32x4* a1 = reinterpret_cast<const f32x4*>(gimg + row * L::GA_STRIDE + (16 * pc + 4 * gg) * 3 * 4);
-          const f32x4* a0 = reinterpret_cast<const f32x4*>(gimg + L::GA_BYTES + row * L::GB_ROW + (16 * pc + 4 * gg) * 4);
+          const unsigned char* r2 = gimg + row * L::GA_STRIDE + (3 * H + (16 * pc + 4 * gg) * 5) * ES;
+          const unsigned char* r1 = gimg + row * L::GA_STRIDE + (16 * pc + 4 * gg) * 3 * ES;
+          const unsigned char* r0 = gimg + L::GA_BYTES + row * L::GB_ROW + (16 * pc + 4 * gg) * ES;
+          if constexpr (!IO16) {
 #pragma unroll
-          for (int u = 0; u < 5; ++u) { const f32x4 v = a2[u]; q2[4 * u] = v[0]; q2[4 * u + 1] = v[1]; q2[4 * u + 2] = v[2]; q2[4 * u + 3] = v[3]; }
+            for (int u = 0; u < 5; ++u) { const f32x4 v = reinterpret_cast<const f32x4*>(r2)[u]; q2[4 * u] = v[0]; q2[4 * u + 1] = v[1]; q2[4 * u + 2] = v[2]; q2[4 * u + 3] = v[3]; }
 #pragma unroll
-          for (int u = 0; u < 3; ++u) { const f32x4 v = a1[u]; q1[4 * u] = v[0]; q1[4 * u + 1] = v[1]; q1[4 * u + 2] = v[2]; q1[4 * u + 3] = v[3]; }
-          { const f32x4 v = a0[0]; q0[0] = v[0]; q0[1] = v[1]; q0[2] = v[2]; q0[3] = v[3]; }
+            for (int u = 0; u < 3; ++u) { const f32x4 v = reinterpret_cast<const f32x4*>(r1)[u]; q1[4 * u] = v[0]; q1[4 * u + 1] = v[1]; q1[4 * u + 2] = v[2]; q1[4 * u + 3] = v[3]; }
+            { const f32x4 v = reinterpret_cast<const f32x4*>(r0)[0]; q0[0] = v[0]; q0[1] = v[1]; q0[2] = v[2]; q0[3] = v[3]; }
+          } else {  // 4 bf16 per 8-byte read, widened (exact)
+            auto widen = [](const uint2 v, float* o) {
+              o[0] = __builtin_bit_cast(float, v.x << 16); o[1] = __builtin_bit_cast(float, v.x & 0xffff0000u);
+              o[2] = __builtin_bit_cast(float, v.y << 16); o[3] = __builtin_bit_cast(float, v.y & 0xffff0000u);
+            };
+#pragma unroll
+            for (int u = 0; u < 5; ++u) widen(reinterpret_cast<const uint2*>(r2)[u], q2 + 4 * u);
+#pragma unroll
+            for (int u = 0; u < 3; ++u) widen(reinterpret_cast<const uint2*>(r1)[u], q1 + 4 * u);
+            widen(reinterpret_cast<const uint2*>(r0)[0], q0);
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
         float y[9], dist;
         if constexpr (LMAX == 2) edge_sh(ps, pd, y, dist); else edge_sh1(ps, pd, y, dist);
-        auto put4 = [&](const int fr, const float (&f)[4]) {
-          uint32_t h0, l0, h1, l1;
-          split2_f16(f[0], f[1], h0, l0);
-          split2_f16(f[2], f[3], h1, l1);
-          *reinterpret_cast<uint2*>(b1 + fr * L::FRB) = uint2{h0, h1};
-          *reinterpret_cast<uint2*>(b1 + fr * L::FRB + 1024) = uint2{l0, l1};
-        };
+        auto put4 = [&](const int fr, const float (&f)[4]) { ws_put4<IO16>(b1 + fr * L::FRB, f); };
         auto degree = [&](auto ltag, float* q) {  // q[r * D1 + a]: channel r of the piece, component a
           constexpr int L1 = decltype(ltag)::value, D1 = 2 * L1 + 1;
+          if constexpr (!IO16) {
 #pragma unroll
-          for (int i = 0; i < 4 * D1; ++i) q[i] *= xs;   // the operand scale, once
+            for (int i = 0; i < 4 * D1; ++i) q[i] *= xs;   // the operand scale, once
+          }
 #pragma unroll
           for (int a = 0; a < D1; ++a) {
             const float f[4] = {q[a], q[D1 + a], q[2 * D1 + a], q[3 * D1 + a]};
@@ -658,7 +686,6 @@ __device__ __forceinline__ void ws_run(const WsArgs& A, unsigned char* smem) {
             put4(L::frag_ff(L1), f);
           }
         };
-        static_assert(!IO16, "fp32 image");
         degree(I2{}, q2);
         degree(I1{}, q1);
         degree(I0{}, q0);
@@ -809,14 +836,7 @@ __device__ __forceinline__ void ws_run(const WsArgs& A, unsigned char* smem) {
         const f32x4* nt = reinterpret_cast<const f32x4*>(n1tab) + g;  // norm slot s at nt[4 s]; carries 1 / (sw1 xs)
         // this wave's half (tile t: k slots 4 t .. 4 t + 3) of every fragment lane: 8 bytes hi, 8 bytes lo
         unsigned char* b2 = smem + L::o_b2 + lane * 16 + 8 * O::t;
-        auto put4 = [&](const int fr, const float (&f)[4]) {
-          uint32_t h0, l0, h1, l1;
-          split2_f16(f[0], f[1], h0, l0);
-          split2_f16(f[2], f[3], h1, l1);
-          *reinterpret_cast<uint2*>(b2 + fr * L::FRB) = uint2{h0, h1};
-          *reinterpret_cast<uint2*>(b2 + fr * L::FRB + 1024) = uint2{l0, l1};
-        };
-        static_assert(!IO16, "fp32 fragments");
+        auto put4 = [&](const int fr, const float (&f)[4]) { ws_put4<IO16>(b2 + fr * L::FRB, f); };
         if constexpr (O::tS >= 0) {
           const f32x4 nv = nt[4 * O::tS];
           float f[4];
@@ -952,29 +972,33 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 // ------------------------------------------------------------------------------------------------------------------
 // host
 // ------------------------------------------------------------------------------------------------------------------
-bool msg_ws_supported(int lmax, int hidden, int dtype) { return lmax == 2 && hidden == 32 && (dtype == E3_F32); }
+bool msg_ws_supported(int lmax, int hidden, int dtype) {
+  return lmax == 2 && hidden == 32 && (dtype == E3_F32 || dtype == E3_BF16);
+}
 
 int msg_ws_launch(int lmax, int hidden, int dtype, const void* h, int64_t ldh, int64_t N, const float* pos4, const int32_t* src,
                   const int32_t* dst, int64_t E, const void* packed, const float* in_scale, const float* premix, float* out,
                   int64_t ldo, int chunk_edges, hipStream_t stream) {
   if (!msg_ws_supported(lmax, hidden, dtype)) return E3_ERR_UNSUPPORTED;
-  using L = Ws<2, 2, false>;
   if (E > 0x7fffffffLL - 65536) return E3_ERR_UNSUPPORTED;  // 32-bit edge arithmetic with chunk head room
+  const int io = dtype == E3_BF16 ? 1 : 0;
+  const void* kern = io ? (const void*)msg_ws_kernel<2, 2, true> : (const void*)msg_ws_kernel<2, 2, false>;
+  const int lds = io ? Ws<2, 2, true>::total : Ws<2, 2, false>::total;
   int dev = 0;
   E3_HIP_CHECK(hipGetDevice(&dev));
   static std::mutex mu;
-  static int cus_of[64];
+  static int cus_of[64][2];
   int cus = 0;
   {
     std::lock_guard<std::mutex> lock(mu);
     if (dev < 0 || dev >= 64) return E3_ERR_INVALID_ARG;
-    if (cus_of[dev] == 0) {  // once per device: the kernel needs its LDS image admitted
-      E3_HIP_CHECK(hipFuncSetAttribute((const void*)msg_ws_kernel<2, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, L::total));
+    if (cus_of[dev][io] == 0) {  // once per device and storage type: the kernel needs its LDS image admitted
+      E3_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
       int n = 0;
       if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-      cus_of[dev] = n;
+      cus_of[dev][io] = n;
     }
-    cus = cus_of[dev];
+    cus = cus_of[dev][io];
   }
   int chunk = chunk_edges > 0 ? (chunk_edges + 15) / 16 * 16 : 256;
   const int64_t nchunks = (E + chunk - 1) / chunk;
@@ -983,8 +1007,8 @@ int msg_ws_launch(int lmax, int hidden, int dtype, const void* h, int64_t ldh, i
   const float* hmax = premix + (size_t)N * MsgGeom<2, 2>::UD;  // per-node row maxima behind the table (e3_msg_premix)
   WsArgs a = {h, ldh, reinterpret_cast<const float4*>(pos4), src, dst, E, static_cast<const float*>(packed), premix, hmax,
               in_scale, out, ldo, chunk};
-  hipLaunchKernelGGL((msg_ws_kernel<2, 2, false>), dim3(nwg), dim3(512), L::total, stream, a);
-  E3_HIP_CHECK(hipGetLastError());
+  void* args[] = {&a};
+  if (hipLaunchKernel(kern, dim3(nwg), dim3(512), args, lds, stream) != hipSuccess) return E3_ERR_HIP;
   return E3_OK;
 }
 

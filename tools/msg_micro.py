@@ -22,6 +22,8 @@ layer = SEGNNLayer(H, lmax).to(dev)
 D = H * (lmax + 1) ** 2
 h = torch.randn(N, D, device=dev)
 sc = ops.pow2_scale([h])
+if os.environ.get("DT") == "bf16":   # bf16 storage (BASELINE.json configs[2]): no operand scales
+    layer = layer.bfloat16(); h = h.bfloat16(); sc = None
 edges = None
 if os.environ.get("ZERO_IDX"):   # every h[src] gather hits row 0
     edges = (torch.zeros_like(g.src), g.dst)
