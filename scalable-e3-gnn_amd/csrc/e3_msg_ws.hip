@@ -134,16 +134,28 @@ __device__ __forceinline__ void ws_barrier() { asm volatile("s_waitcnt lgkmcnt(0
 __device__ __forceinline__ int sgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // 4 values = half of a fragment lane (k slots 4 t .. 4 t + 3): fp32 storage: fp16 (hi, lo) halves, 8 bytes each (lo 1 KiB
 // behind hi); bf16 storage: 4 bf16, rounded once
+// (s v0, s v1) -> fp16 pairs hi = rne16(s v), lo = rne16(s v - hi) in FOUR instructions: v_fma_mix{lo,hi}_f16 multiply in fp32,
+// round once to fp16 and write one half of the destination (split2_f16 + a separate scale multiply compile to eight).
+// s is a power of two, so s v is exact and both roundings are the ones of split2_f16.
+__device__ __forceinline__ void split2_f16_scaled(const float v0, const float v1, const float s, uint32_t& hi, uint32_t& lo) {
+  uint32_t h, l;
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(h) : "v"(s), "v"(v0));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(h) : "v"(s), "v"(v1));
+  asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l) : "v"(s), "v"(v0), "v"(h));
+  asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(s), "v"(v1), "v"(h));
+  hi = h; lo = l;
+}
+// f * s (s a power of two; bf16 storage: s = 1, ignored)
 template <bool IO16>
-__device__ __forceinline__ void ws_put4(unsigned char* dst, const float (&f)[4]) {
+__device__ __forceinline__ void ws_put4(unsigned char* dst, const float (&f)[4], const float s) {
   if constexpr (IO16) {
     const uint32_t a = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{f[0], f[1]}, bf16x2_t));
     const uint32_t b = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{f[2], f[3]}, bf16x2_t));
     *reinterpret_cast<uint2*>(dst) = uint2{a, b};
   } else {
     uint32_t h0, l0, h1, l1;
-    split2_f16(f[0], f[1], h0, l0);
-    split2_f16(f[2], f[3], h1, l1);
+    split2_f16_scaled(f[0], f[1], s, h0, l0);
+    split2_f16_scaled(f[2], f[3], s, h1, l1);
     *reinterpret_cast<uint2*>(dst) = uint2{h0, h1};
     *reinterpret_cast<uint2*>(dst + 1024) = uint2{l0, l1};
   }
@@ -660,13 +672,9 @@ __device__ __forceinline__ void ws_run(const WsArgs& A, unsigned char* smem) {
         __builtin_amdgcn_sched_barrier(0);
         float y[9], dist;
         if constexpr (LMAX == 2) edge_sh(ps, pd, y, dist); else edge_sh1(ps, pd, y, dist);
-        auto put4 = [&](const int fr, const float (&f)[4]) { ws_put4<IO16>(b1 + fr * L::FRB, f); };
+        auto put4 = [&](const int fr, const float (&f)[4]) { ws_put4<IO16>(b1 + fr * L::FRB, f, xs); };  // (operand scale in the split)
         auto degree = [&](auto ltag, float* q) {  // q[r * D1 + a]: channel r of the piece, component a
           constexpr int L1 = decltype(ltag)::value, D1 = 2 * L1 + 1;
-          if constexpr (!IO16) {
-#pragma unroll
-            for (int i = 0; i < 4 * D1; ++i) q[i] *= xs;   // the operand scale, once
-          }
 #pragma unroll
           for (int a = 0; a < D1; ++a) {
             const float f[4] = {q[a], q[D1 + a], q[2 * D1 + a], q[3 * D1 + a]};
@@ -836,14 +844,14 @@ __device__ __forceinline__ void ws_run(const WsArgs& A, unsigned char* smem) {
         const f32x4* nt = reinterpret_cast<const f32x4*>(n1tab) + g;  // norm slot s at nt[4 s]; carries 1 / (sw1 xs)
         // this wave's half (tile t: k slots 4 t .. 4 t + 3) of every fragment lane: 8 bytes hi, 8 bytes lo
         unsigned char* b2 = smem + L::o_b2 + lane * 16 + 8 * O::t;
-        auto put4 = [&](const int fr, const float (&f)[4]) { ws_put4<IO16>(b2 + fr * L::FRB, f); };
+        auto put4 = [&](const int fr, const float (&f)[4]) { ws_put4<IO16>(b2 + fr * L::FRB, f, srow); };
         if constexpr (O::tS >= 0) {
           const f32x4 nv = nt[4 * O::tS];
           float f[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float sv = accS[r] * nv[r];
-            f[r] = sv * sigmoid_(sv) * srow;
+            f[r] = sv * sigmoid_(sv);
           }
           put4(L::frag(0, 0), f);
         }
@@ -852,7 +860,7 @@ __device__ __forceinline__ void ws_run(const WsArgs& A, unsigned char* smem) {
           const f32x4 gn = nt[4 * O::tG];
           float gt[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) gt[r] = sigmoid_(accG[r] * gn[r]) * srow;
+          for (int r = 0; r < 4; ++r) gt[r] = sigmoid_(accG[r] * gn[r]);
           float y9[9];
 #pragma unroll
           for (int i = 0; i < 9; ++i) y9[i] = y[i];
