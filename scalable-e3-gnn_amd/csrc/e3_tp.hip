@@ -688,10 +688,7 @@ int e3_tp_fused_supported(const e3_tp_plan* plan, int gate) {
   if (!plan || !plan->fast.usable) return 0;
   if (!gate) return 1;
   if (!plan->fast.gate_layout) return 0;
-  const FDev& d = plan->fast.dev;
-  const int nb = (d.NT[1] > 0) + (d.NT[2] > 0);
-  return (d.NT[0] == 1 + nb && d.M[0] == 32 * (1 + nb) && (!d.NT[1] || d.M[1] == 32) && (!d.NT[2] || d.M[2] == 32) &&
-          d.NT[1] <= 1 && d.NT[2] <= 1) ? 1 : 0;
+  return e3::fast_gate_shape_ok(&plan->fast) ? 1 : 0;
 }
 
 }  // extern "C"

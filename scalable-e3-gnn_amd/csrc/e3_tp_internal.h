@@ -58,6 +58,8 @@ int fast_forward(const TpFast* F, const e3_tp_segment* segs, int nseg, int D1, c
 void fast_note_kernel(const char* name);
 const char* fast_last_kernel();
 
+// out irreps are a gated layout the fused gate epilogue handles ([H x0e | (nb H) x0e | H x1o (| H x2e)], H % 16 == 0)
+bool fast_gate_shape_ok(const TpFast* F);
 // does the 16-row kernel have an instantiation for this plan?
 bool r16_supported(const TpFast* F);
 // 16-row kernel (e3_tp_mfma_r16.hip): 1 = launched, 0 = no instantiation, < 0 = -status

@@ -67,6 +67,16 @@ __global__ void fast_pack_kernel(const T* w0, const T* w1, const T* w2, const T*
   }
 }
 
+// gated out irreps [H x0e | (nb H) x0e | H x1o (| H x2e)] with H a multiple of 16 (the fused gate epilogue of the 16-row kernel
+// finds the gate of channel c of block b at scalar channel b H + c: same lane, same register)
+bool fast_gate_shape_ok(const TpFast* F) {
+  const FDev& d = F->dev;
+  const int nb = (d.NT[1] > 0) + (d.NT[2] > 0);
+  if (!F->gate_layout || nb == 0 || d.M[0] % (1 + nb)) return false;
+  const int H = d.M[0] / (1 + nb);
+  return H > 0 && H % 16 == 0 && (!d.NT[1] || d.M[1] == H) && (!d.NT[2] || d.M[2] == H);
+}
+
 int fast_plan_init(TpFast* F, const int n[6], const int M[6], int lmax_sh, int Dout, int Dy,
                    const std::vector<std::array<int, 4>>& in_blocks /* l,p,mul,col */,
                    const std::vector<TpPath>* paths_by_class /*[6]*/, const int ocol_off[6]) {
@@ -215,12 +225,7 @@ int fast_forward(const TpFast* F, const e3_tp_segment* segs, int nseg, int D1, c
     while (sidx + 1 < nseg && ch.col >= sa.col0[sidx + 1]) ++sidx;
     if (ch.col + cw > sa.col0[sidx + 1]) return E3_ERR_INVALID_ARG;
   }
-  if (gate) {
-    const int nb = (d.NT[1] > 0) + (d.NT[2] > 0);
-    if (!F->gate_layout || d.NT[0] != 1 + nb || d.M[0] != 32 * (1 + nb) || (d.NT[1] && d.M[1] != 32) || (d.NT[2] && d.M[2] != 32) ||
-        d.NT[1] > 1 || d.NT[2] > 1)
-      return E3_ERR_UNSUPPORTED;
-  }
+  if (gate && !fast_gate_shape_ok(F)) return E3_ERR_UNSUPPORTED;
   const int r = fast_forward_r16(F, &sa, in2, ld2, packed, out, ldo, B, gate, io16 ? 1 : 0, ocol_tab, in_scale, s);
   if (r == 1) return E3_OK;
   return r < 0 ? -r : E3_ERR_UNSUPPORTED;

@@ -175,7 +175,12 @@ __device__ __forceinline__ void run16(const float (&x)[8][2 * L1 + 1], const boo
 // NT0/NT1/NT2 = 32-channel tile counts per output degree as in the other kernels (each = two 16-channel MFMA tiles)
 // waves per SIMD the register allocation is capped for: 2 with l_max = 2 outputs (88 accumulator registers), 3 with the
 // l_max = 1 products (40)
-constexpr int r16_waves_per_simd(int nt2) { return nt2 > 0 ? 2 : 3; }  // (4 spills 24-49 VGPRs: 61 -> 66 ms)
+// accumulators (f32x4 per lane): 2 NT0 + 6 NT1 + 10 NT2.  Up to 22 (hidden 32: 88 registers) two waves per SIMD for l_max = 2,
+// three for l_max = 1 (4 spills 24-49 VGPRs: 61 -> 66 ms); above that (hidden 64: 44 = 176 registers) one wave with the whole file
+constexpr int r16_acc(int nt0, int nt1, int nt2) { return 2 * nt0 + 6 * nt1 + 10 * nt2; }
+constexpr int r16_waves_per_simd(int nt0, int nt1, int nt2) {
+  return r16_acc(nt0, nt1, nt2) > 22 ? 1 : ((nt2 > 0 || r16_acc(nt0, nt1, nt2) > 12) ? 2 : 3);
+}
 // per-wave chunk buffer (dwords): the larger of a staged chunk (input degree lin) and the out tile (output degree lout):
 // 16 rows x (32 channels x (2l + 1) + 4)
 constexpr int r16_chunk(int lin, int lout) { return 16 * (32 * (2 * (lin > lout ? lin : lout) + 1) + 4); }
@@ -186,7 +191,7 @@ constexpr int r16_max(std::initializer_list<int> v) {
 }
 
 template <int LSH, int NT0, int NT1, int NT2, bool GATE, int MODE, bool SCAT, int... L1S>
-__global__ __launch_bounds__(256, r16_waves_per_simd(NT2)) void tp_fwd_mfma_r16_kernel(SegArgs segs, const float* __restrict__ in2, int64_t ld2,
+__global__ __launch_bounds__(256, r16_waves_per_simd(NT0, NT1, NT2)) void tp_fwd_mfma_r16_kernel(SegArgs segs, const float* __restrict__ in2, int64_t ld2,
                                                                   const float* __restrict__ packed, void* __restrict__ outv,
                                                                   int64_t ldo, int64_t B, const FDev* __restrict__ dp,
                                                                   const FChunk* __restrict__ chunks,
@@ -475,27 +480,53 @@ __global__ __launch_bounds__(256, r16_waves_per_simd(NT2)) void tp_fwd_mfma_r16_
     using I5 = std::integral_constant<int, 5>;
     // accumulator element of 32-channel tile t32, lane value q (see chan_of): 16-tile 2*t32 + (q >> 2), register q & 3
     if constexpr (GATE) {
+      // out irreps [H x 0e | H x 0e per gated block | H x 1o | H x 2e], H = 16 HT channels (hidden 16 / 32 / 64 ...): scalar
+      // channel H l + c gates channel c of degree l.  A lane's 8 channels of a 32-channel tile sit in two 16-channel
+      // accumulator tiles, and H l is a multiple of 16, so the gate of a value is in the SAME lane and register of a0.
+      constexpr int NL = (NT1 > 0 ? 1 : 0) + (NT2 > 0 ? 1 : 0);
+      constexpr int HT = (2 * NT0) / (1 + NL);       // 16-channel tiles per block
+      constexpr int Hh = 16 * HT;
+      constexpr int NTS = (Hh + 31) / 32;             // 32-channel tiles of the plain scalars (= of every gated block)
+      // (the macro below instantiates the gated form for every tile shape; shapes that are no gated layout -- e.g. the
+      // update product #2 -- are never launched with GATE and compile to an empty epilogue)
+      constexpr bool GOK = HT > 0 && (NT1 == 0 || NT1 == NTS) && (NT2 == 0 || NT2 == NTS) && (1 + NL) * HT <= 2 * NT0;
+      if constexpr (GOK) {
       const float* nrm0 = nrm + ocl[cOoff[0]];
-      emit(I1{}, [&](int q, int) { const float s = a0[q >> 2][0][q & 3] * nrm0[chan_of(q)]; return s * sigmoid_(s); },
-           [&](int lc) { return lc; }, [&](int) { return -1; }, 32, true);
-      int ocol = 32;
-      if constexpr (NT1 > 0) {
-        float gq[8];
+      // a0 tile 2 t + (q >> 2) of block `blk` (0: scalars, 1 / 2: gates); tiles beyond the block hold other channels: masked
+      auto a0_of = [&](auto btag, auto ttag, int q) {
+        constexpr int BLK = decltype(btag)::value, T32 = decltype(ttag)::value;
+        return (q >> 2) == 0 ? a0[(BLK * HT + 2 * T32 < 2 * NT0) ? BLK * HT + 2 * T32 : 0][0][q & 3]
+                             : a0[(BLK * HT + 2 * T32 + 1 < 2 * NT0) ? BLK * HT + 2 * T32 + 1 : 0][0][q & 3];
+      };
+      auto per_tile = [&](auto ttag) {
+        constexpr int T32 = decltype(ttag)::value;
+        constexpr int W = Hh - 32 * T32 < 32 ? Hh - 32 * T32 : 32;   // channels of this tile that exist
+        using B0 = std::integral_constant<int, 0>;
+        emit(I1{}, [&](int q, int) {
+               const float s = a0_of(B0{}, ttag, q) * nrm0[32 * T32 + chan_of(q)];
+               return s * sigmoid_(s);
+             },
+             [&](int lc) { return 32 * T32 + lc; }, [&](int) { return -1; }, W, true);
+        if constexpr (NT1 > 0) {
+          using B1 = std::integral_constant<int, 1>;
+          float gq[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) gq[q] = sigmoid_(a0[2 + (q >> 2)][0][q & 3] * nrm0[32 + chan_of(q)]);
-        const int nb = ocl[cOoff[1]];
-        emit(I3{}, [&](int q, int c) { return gq[q] * a1[q >> 2][c][q & 3]; }, [&](int lc) { return ocol + lc; },
-             [&](int lc) { return nb + lc; }, 96, true);
-        ocol += 96;
-      }
-      if constexpr (NT2 > 0) {
-        constexpr int G2 = (NT1 > 0) ? 2 : 1;
-        float gq[8];
+          for (int q = 0; q < 8; ++q) gq[q] = sigmoid_(a0_of(B1{}, ttag, q) * nrm0[Hh + 32 * T32 + chan_of(q)]);
+          const int nb = ocl[cOoff[1]] + 96 * T32;
+          emit(I3{}, [&](int q, int c) { return gq[q] * a1[2 * T32 + (q >> 2)][c][q & 3]; },
+               [&](int lc) { return Hh + 96 * T32 + lc; }, [&](int lc) { return nb + lc; }, 3 * W, true);
+        }
+        if constexpr (NT2 > 0) {
+          using B2 = std::integral_constant<int, (NT1 > 0) ? 2 : 1>;
+          float gq[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) gq[q] = sigmoid_(a0[2 * G2 + (q >> 2)][0][q & 3] * nrm0[32 * G2 + chan_of(q)]);
-        const int nb = ocl[cOoff[2]];
-        emit(I5{}, [&](int q, int c) { return gq[q] * a2[q >> 2][c][q & 3]; }, [&](int lc) { return ocol + lc; },
-             [&](int lc) { return nb + lc; }, 160, true);
+          for (int q = 0; q < 8; ++q) gq[q] = sigmoid_(a0_of(B2{}, ttag, q) * nrm0[B2::value * Hh + 32 * T32 + chan_of(q)]);
+          const int nb = ocl[cOoff[2]] + 160 * T32;
+          emit(I5{}, [&](int q, int c) { return gq[q] * a2[2 * T32 + (q >> 2)][c][q & 3]; },
+               [&](int lc) { return Hh * (NT1 > 0 ? 4 : 1) + 160 * T32 + lc; }, [&](int lc) { return nb + lc; }, 5 * W, true);
+        }
+      };
+      for_each_index(per_tile, std::make_index_sequence<NTS>{});
       }
     } else {
       auto tile = [&](auto dtag, int l3, int t, auto val) {
@@ -545,6 +576,18 @@ static const std::vector<R16KernelEntry>& r16_kernels() {
       E3_R16(2, 0, 1, 0, false, 0, 1, 2),              //          readout
       E3_R16(1, 1, 1, 0, false, 0, 1),                 // l_max 1: update TP #2 / embedding
       E3_R16(1, 0, 1, 0, false, 0, 1),                 //          readout
+      // hidden 16 (chunks of 16 channels: one dead K half) -- the other products share the hidden-32 entries above
+      E3_R16(2, 2, 1, 1, false, 0, 1, 2, 0, 1, 2),     // l_max 2: update TP #1
+      E3_R16(1, 1, 1, 0, false, 0, 1, 0, 1),           // l_max 1: update TP #1
+      // hidden 64 (two 32-channel chunks per degree and segment)
+      E3_R16(2, 6, 2, 2, false, 0, 0, 1, 1, 2, 2, 0, 0, 1, 1, 2, 2),   // l_max 2: update TP #1
+      E3_R16(2, 2, 2, 2, false, 0, 0, 1, 1, 2, 2),     //          update TP #2
+      E3_R16(2, 2, 2, 2, false, 0, 1),                 //          embedding
+      E3_R16(2, 0, 1, 0, false, 0, 0, 1, 1, 2, 2),     //          readout
+      E3_R16(1, 4, 2, 0, false, 0, 0, 1, 1, 0, 0, 1, 1),   // l_max 1: update TP #1
+      E3_R16(1, 2, 2, 0, false, 0, 0, 1, 1),           //          update TP #2
+      E3_R16(1, 2, 2, 0, false, 0, 1),                 //          embedding
+      E3_R16(1, 0, 1, 0, false, 0, 0, 1, 1),           //          readout
   };
   return k;
 }
@@ -572,7 +615,7 @@ constexpr int kR16Waves = 4;  // per workgroup; two or three workgroups per CU
 
 bool r16_supported(const TpFast* F) {
   return r16_find(F) != nullptr &&
-         (size_t)r16_waves_per_simd(F->dev.NT[2]) * r16_lds_bytes(F, kR16Waves) <= (size_t)kFastLds;
+         (size_t)r16_waves_per_simd(F->dev.NT[0], F->dev.NT[1], F->dev.NT[2]) * r16_lds_bytes(F, kR16Waves) <= (size_t)kFastLds;
 }
 
 // 1 = launched, 0 = not applicable, < 0 = -status
@@ -586,7 +629,7 @@ int fast_forward_r16(const TpFast* F, const void* sa_, const void* in2, int64_t 
   if (scat && (io16 || !gate || !e->fn_scat)) return 0;
   const void* fn = scat ? e->fn_scat : e->fn[io16 ? 1 : 0][gate ? 1 : 0];
   const size_t lds_bytes = r16_lds_bytes(F, kR16Waves);
-  if ((size_t)r16_waves_per_simd(d.NT[2]) * lds_bytes > (size_t)kFastLds) return 0;
+  if ((size_t)r16_waves_per_simd(d.NT[0], d.NT[1], d.NT[2]) * lds_bytes > (size_t)kFastLds) return 0;
   {  // the dynamic-LDS limit is a per-device attribute of the function
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return -E3_ERR_HIP;
@@ -599,7 +642,7 @@ int fast_forward_r16(const TpFast* F, const void* sa_, const void* in2, int64_t 
     }
   }
   const int64_t ntiles = (B + 15) / 16;
-  const int grid = (int)std::min<int64_t>((ntiles + kR16Waves - 1) / kR16Waves, 256 * r16_waves_per_simd(d.NT[2]));
+  const int grid = (int)std::min<int64_t>((ntiles + kR16Waves - 1) / kR16Waves, 256 * r16_waves_per_simd(d.NT[0], d.NT[1], d.NT[2]));
   const float* in2f = (const float*)in2;
   const float* pk = (const float*)packed;
   void* outf = out;

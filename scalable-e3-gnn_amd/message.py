@@ -116,6 +116,22 @@ class FusedMessage:
         hmax[rows] = m
         return m.max() if m.numel() else torch.zeros((), device=h.device)
 
+    def executed_flops_per_edge(self) -> int:
+        """Flops the edge kernel actually EXECUTES on the matrix pipe per edge and product pass: the dst half and the distance
+        channel of product #1 are contracted once per NODE (pre-mix launch), so the edge kernel's K is H, not 2H + 1."""
+        H, L = self.hidden, self.lmax
+        fl = 0
+        for _tp in (1, 2):
+            for l3 in range(L + 1):
+                M = H * (1 + L) if l3 == 0 else H
+                for l1 in range(L + 1):
+                    for l2 in range(L + 1):
+                        if abs(l1 - l2) <= l3 <= l1 + l2 and (l1 + l2 + l3) % 2 == 0:
+                            # mix-first paths: 2 l1 + 1 groups; feature-first (scalar outputs from l1 > 0): one group
+                            groups = 1 if (l3 == 0 and l1 > 0) else (2 * l1 + 1)
+                            fl += 2 * H * M * groups
+        return fl
+
     def forward(self, h: torch.Tensor, g: RadiusGraph, msg1, msg2, in_scale: torch.Tensor | None = None, edges=None,
                 cont=None, return_state: bool = False):
         """h [N, width] fp32 | bf16 (Morton order of ``g``) -> aggregated messages [N, width] in h's dtype (the sums are
@@ -175,7 +191,10 @@ class FusedMessage:
             if t0 is not None:
                 # algorithmic bytes: h read once, positions, the two index columns, aggregated rows written once
                 nb = esz * N * W + 16 * N + 8 * E + 4 * N * W
+                ws = bool(self.lmax == 2 and self.hidden == 32 and int(self.tiles_per_block) >= 0)
                 profiling.end(f"msg_fused lmax={self.lmax} H={self.hidden} E={E} {io}", E, nb, t0,
-                              flops=self.flops_per_edge() * E, kernel="e3::msg_fused_kernel" + mode)
+                              flops=self.flops_per_edge() * E,
+                              kernel=("e3::msg_ws_kernel" if ws else "e3::msg_fused_kernel") + mode,
+                              executed_flops=self.executed_flops_per_edge() * E)
         # fp32 sums; callers in bf16 storage round once (SEGNNLayer)
         return (out, (out, premix)) if return_state else out

@@ -69,10 +69,19 @@ class SEGNNLayer(nn.Module):
         return ops.gate(t, H, H) if self.lmax == 1 else ops.gate_blocks(t, H, [(1, H), (2, H)])
 
     def fused_available(self) -> bool:
-        """Static part only (shapes with an MFMA instantiation); grad mode is looked at on every call."""
+        """Static part only (shapes with an MFMA instantiation); grad mode is looked at on every call.  True when the
+        per-product fused kernels exist for BOTH message products and the update product."""
         f = getattr(self, "_fused_ok", None)
         if f is None:
             f = self._fused_ok = all(tp.fused_supported(True) for tp in (self.msg1, self.msg2, self.upd1))
+        return f
+
+    def fused_update_available(self) -> bool:
+        """The update product alone (gather + concat + TP + gate in one launch) -- enough when the one-launch message kernel
+        handles the messages (hidden 16 / 64: only the node-level products have per-product MFMA instantiations)."""
+        f = getattr(self, "_fused_upd_ok", None)
+        if f is None:
+            f = self._fused_upd_ok = bool(self.upd1.fused_supported(True))
         return f
 
     def forward(self, h, g: RadiusGraph, Y, d, A, h_scale=None, halo=None, split=None):
@@ -90,11 +99,12 @@ class SEGNNLayer(nn.Module):
                           "torch.no_grad() to get the fast path", RuntimeWarning, stacklevel=2)
         f32 = h.dtype == torch.float32
         r16 = self.fused and inference and self.fused_available()   # per-TP fused kernels (gather + TP + gate)
-        if h.dtype == torch.bfloat16 and not r16:
-            raise RuntimeError("bf16 storage needs the fused MFMA kernels (inference, hidden = 32)")
         # ---- message function -> aggregated messages a [N, width] ----
         one_launch = (self.fused and inference and self.fuse_message and self.fuse_scatter and self._msg is not None and
                       self._msg.supports(h.dtype))
+        r16u = self.fused and inference and (r16 or (one_launch and self.fused_update_available()))   # update product
+        if h.dtype == torch.bfloat16 and not ((one_launch or r16) and r16u):
+            raise RuntimeError("bf16 storage needs the fused MFMA kernels (inference; hidden 32, or 64 at l_max = 2)")
         if halo is not None and not (one_launch and split is not None):
             halo.exchange(h)  # blocking refresh of the ghost rows, in place
         if one_launch and halo is not None and split is not None:
@@ -141,7 +151,7 @@ class SEGNNLayer(nn.Module):
             m = self._gate(self.msg2(m, Y))
             a = ops.segment_sum(m, g)
         # ---- node update ----
-        if r16:
+        if r16u:
             # operand scale of [h | a]: h's is known (the previous layer returned it), so only `a` is scanned
             sc = None
             if f32 and h_scale is not None and halo is None:

@@ -74,6 +74,20 @@ class TPPlan:
     def fused_supported(self, gate: bool) -> bool:
         return bool(_lib.load().e3_tp_fused_supported(self.handle(), 1 if gate else 0))
 
+    def gated_width(self):
+        """Width of the gated output for out irreps ``[H x0e | (nb H) x0e | H x1o (| H x2e)]`` (natural parity, H a
+        multiple of 16): the nb H gate scalars disappear.  None when the out irreps do not have that shape."""
+        blocks = self._blocks[2]
+        if len(blocks) < 3 or any(b[0] != 0 or b[1] != 1 for b in blocks[:2]):
+            return None
+        H, gates = blocks[0][2], blocks[1][2]
+        gated = blocks[2:]
+        if H % 16 or gates != H * len(gated) or any(b[2] != H for b in gated):
+            return None
+        if [(b[0], b[1]) for b in gated] not in ([(1, -1)], [(1, -1), (2, 1)]):
+            return None
+        return H + sum((2 * b[0] + 1) * H for b in gated)
+
     def packed(self, ws, ns, dtype, device):
         """ws / ns: 6-entry lists (per class) of optional tensors.  The packed buffer is rebuilt when a parameter or
         buffer was replaced or modified through autograd-visible ops (``_version``); in-place edits through ``.data``
@@ -140,9 +154,9 @@ class TPPlan:
                 assert t.shape[0] == B
         width = self.out_dim
         if gate:
-            width = {160: 128, 352: 288, 224: 192}.get(self.out_dim)
+            width = self.gated_width()
             if width is None:
-                raise RuntimeError("gate fusion needs out irreps [32x0e | 32x0e per block | 32x1o | 32x2e]")
+                raise RuntimeError("gate fusion needs out irreps [Hx0e | (blocks H)x0e | Hx1o (| Hx2e)], H a multiple of 16")
         if scatter is not None:
             row_node, n_nodes = scatter
             if not gate:

@@ -32,14 +32,19 @@ def _case(N, H, L, lmax, seed):
     return model, g, xs, args, geo
 
 
-@pytest.mark.parametrize("lmax", [2, 1])
-def test_four_layers_bench_mode_meets_1e5(lmax):
-    model, g, xs, args, geo = _case(2000, 32, 4, lmax, seed=5)
+@pytest.mark.parametrize("lmax,H", [(2, 32), (1, 32), (2, 64), (2, 16), (1, 64), (1, 16)])
+def test_four_layers_bench_mode_meets_1e5(lmax, H):
+    N = 2000 if H <= 32 else 1200
+    model, g, xs, args, geo = _case(N, H, 4, lmax, seed=5)
     fwd64 = S.forward_l2 if lmax == 2 else S.forward
     want = fwd64(*args, xs.double().numpy(), *geo)
     with torch.no_grad():
-        assert all(l.fused and l.fused_available() for l in model.layers)
+        # the fast path: one-launch message kernel + MFMA update products (hidden 16 / 64 have per-product MFMA
+        # instantiations for the node-level products only)
+        assert all(l.fused and (l.fused_available() or l.fused_update_available()) for l in model.layers)
+        from scalable_e3_gnn_amd import _lib
         got = model(xs.to(DEV), g).double().cpu().numpy()          # bench default mode
+        assert _lib.load().e3_tp_last_fused_kernel() == b"e3::tp_fwd_mfma_r16_kernel"   # the readout ran on the MFMA kernel
         for l in model.layers:
             l.fused = False                                       # unfused chain on the generic kernels ...
         for m in model.modules():
@@ -50,7 +55,7 @@ def test_four_layers_bench_mode_meets_1e5(lmax):
         exact = model(xs.to(DEV), g).double().cpu().numpy()
     port = (S.forward_l2_torch_cpu if lmax == 2 else S.forward_torch_cpu)(*args, xs.numpy(), *geo)
     e_bench, e_exact, e_port = _rel(got, want), _rel(exact, want), _rel(np.asarray(port, dtype=np.float64), want)
-    print(f"\n4-layer l_max={lmax} H=32 N=2000 vs fp64 oracle: bench mode {e_bench:.2e} | exact fp32 kernels {e_exact:.2e} | "
+    print(f"\n4-layer l_max={lmax} H={H} N={N} vs fp64 oracle: bench mode {e_bench:.2e} | exact fp32 kernels {e_exact:.2e} | "
           f"torch-CPU fp32 port {e_port:.2e}")
     assert e_bench <= 1e-5, e_bench
     assert e_exact <= 1e-5, e_exact
@@ -77,6 +82,23 @@ def test_four_layers_bf16_storage_record():
     err = _rel(got, want)
     print(f"\n4-layer l_max=2 H=32 N=2000 bf16 storage vs fp64 oracle on the bf16-rounded model: {err:.2e}")
     assert np.isfinite(got).all()
+    assert err <= BF16_FOUR_LAYER_BOUND, err
+
+
+def test_four_layers_bf16_storage_hidden64():
+    """bf16 storage end to end at hidden 64 (the bf16 message kernel existed for it; the node-level products now have MFMA
+    instantiations too)."""
+    model, g, xs, args, geo = _case(1200, 64, 4, 2, seed=5)
+    m16 = SEGNN("1x0e+1x1o", 64, "1x1o", 4, lmax=2).to(DEV)
+    m16.load_state_dict(model.state_dict())
+    m16 = m16.bfloat16()
+    params16 = {k: v.detach().float().double().cpu().numpy() for k, v in m16.state_dict().items()}
+    x16 = xs.bfloat16()
+    want = S.forward_l2(params16, *args[1:], x16.double().numpy(), *geo)
+    with torch.no_grad():
+        got = m16(x16.to(DEV), g).double().cpu().numpy()
+    err = _rel(got, want)
+    print(f"\n4-layer l_max=2 H=64 N=1200 bf16 storage vs fp64 oracle on the bf16-rounded model: {err:.2e}")
     assert err <= BF16_FOUR_LAYER_BOUND, err
 
 
