@@ -265,6 +265,24 @@ int e3_tp_forward_fused(const e3_tp_plan* plan, const e3_tp_segment* segs, int n
 int e3_tp_backward(const e3_tp_plan* plan, const void* in1, int64_t ld_in1, const void* in2, int64_t ld_in2,
                    const void* packed, const void* grad_out, int64_t ld_gout, void* grad_in1, int64_t ld_gin1,
                    void* grad_in2, int64_t ld_gin2, void* const grad_weights[6], int64_t B, int dtype, void* stream);
+/*
+ * The same gradients as two thin passes around library GEMMs (the path for large B; fp32 / fp64).  Per output class c3
+ * (D3 = 2 l3 + 1, [rows, cols] = e3_tp_weight_shape):
+ *   e3_tp_backward_operands   features[c3][b, c, r] = sum_{a,q} C[a][q][c] in1[b,k,a] in2[b,q]   ([B, D3, rows], r = path row + k)
+ *                             gout[c3][b, c, w]     = grad_out[b, col(w) + c] * norm[w, c]       ([B, D3, cols])
+ *   caller (any GEMM)         grad_W[c3] = features^T gout  over the B * D3 rows;   t[c3] = gout W[c3]^T   ([B, D3, rows])
+ *   e3_tp_backward_contract   grad_in1[b,k,a] = sum_paths sum_{q,c} C in2[b,q] t[b,c,r]
+ *                             grad_in2[b,q]   = sum_paths sum_{k,a,c} C in1[b,k,a] t[b,c,r]
+ * Arrays are dense, accumulation dtype (fp32 / fp64); a null entry skips that class (features / gout) or means the class
+ * has no weights (t).  grad_in2 follows e3_tp_backward's convention (accumulation dtype; broadcast in2: ld_in2 == 0,
+ * ld_gin2 == 0 and a zero-filled [in2_dim] row, summed with atomics).  Either pointer array of _operands may be null.
+ */
+int e3_tp_backward_operands(const e3_tp_plan* plan, const void* in1, int64_t ld_in1, const void* in2, int64_t ld_in2,
+                            const void* packed, const void* grad_out, int64_t ld_gout, void* const features[6],
+                            void* const gout[6], int64_t B, int dtype, void* stream);
+int e3_tp_backward_contract(const e3_tp_plan* plan, const void* in1, int64_t ld_in1, const void* in2, int64_t ld_in2,
+                            void* const t[6], void* grad_in1, int64_t ld_gin1, void* grad_in2, int64_t ld_gin2,
+                            int64_t B, int dtype, void* stream);
 int e3_tp_fused_supported(const e3_tp_plan* plan, int gate);
 /* kernel family ("e3::tp_fwd_mfma_r16_kernel") that this thread's most recent
  * e3_tp_forward_fused / _scatter / MFMA e3_tp_forward call launched; "" before the first one (diagnostics, bench labels) */

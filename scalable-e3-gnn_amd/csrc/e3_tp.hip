@@ -229,6 +229,37 @@ struct TpGrad {
       }
     }
   }
+  // f[c] = sum_{a,bq} C x[a] y[bq]   (the feature the weight row of channel k multiplies)
+  static __device__ __forceinline__ void feat(const A* x, const A* y, A* f) {
+    if constexpr (ok) {
+#pragma unroll
+      for (int c = 0; c < D3; ++c) {
+        A s = 0;
+#pragma unroll
+        for (int a = 0; a < D1; ++a)
+#pragma unroll
+          for (int bq = 0; bq < D2; ++bq)
+            if (CG<L1, L2, L3>::v[a][bq][c] != 0.0) s += A(CG<L1, L2, L3>::v[a][bq][c]) * x[a] * y[bq];
+        f[c] = s;
+      }
+    }
+  }
+  // from t[c] = sum_w W[k,w] g'[w,c]:  gx[a] += sum_{bq,c} C y[bq] t[c],  gy[bq] += sum_{a,c} C x[a] t[c]
+  static __device__ __forceinline__ void gxy(const A* x, const A* y, const A* t, A* gxa, A* gyb) {
+    if constexpr (ok) {
+#pragma unroll
+      for (int a = 0; a < D1; ++a)
+#pragma unroll
+        for (int bq = 0; bq < D2; ++bq) {
+          A s = 0;
+#pragma unroll
+          for (int c = 0; c < D3; ++c)
+            if (CG<L1, L2, L3>::v[a][bq][c] != 0.0) s += A(CG<L1, L2, L3>::v[a][bq][c]) * t[c];
+          gxa[a] += s * y[bq];
+          gyb[bq] += s * x[a];
+        }
+    }
+  }
   // sum_{a,bq,c} C x[a] y[bq] g[c]
   static __device__ __forceinline__ A gw(const A* x, const A* y, const A* g) {
     A s = 0;
@@ -444,6 +475,199 @@ static int tp_launch_bwd(const e3_tp_plan* plan, const void* in1, int64_t ld1, c
                        (const T*)go, ldg, (A*)gw[0], (A*)gw[1], (A*)gw[2], (A*)gw[3], (A*)gw[4], (A*)gw[5], B, p);
     E3_HIP_CHECK(hipGetLastError());
   }
+  return E3_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// Backward as two thin passes around library GEMMs (the large-B path; the kernels above stay as the small-B / reference
+// path).  Per output class c3 (D3 = 2 l3 + 1, K = weight rows, M = weight cols):
+//   operands:  F[b, c, krow] = sum_{a,bq} C[a][bq][c] x[b,k,a] y[b,bq]      G[b, c, w] = grad_out[b, (w,c)] * norm[w,c]
+//   caller:    grad_W = F^T G   (one GEMM over the B * D3 rows)             T = G W^T  (same shape as F)
+//   contract:  grad_in1[b,k,a] = sum_paths sum_{bq,c} C y[b,bq] T[b,c,wrow+k]   grad_in2[b,bq] = sum_paths sum_{k,a,c} C x T
+// One wave owns one row; lanes run over the channels k of a path, so F / T accesses are contiguous runs.
+// ---------------------------------------------------------------------------------------------------
+struct TpPtr6 { void* p[6]; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void tp_bwd_operands_kernel(const T* __restrict__ in1, int64_t ld1,
+                                                              const T* __restrict__ in2, int64_t ld2,
+                                                              const typename AccOf<T>::type* __restrict__ packed,
+                                                              const T* __restrict__ go, int64_t ldg, TpPtr6 Fp, TpPtr6 Gp,
+                                                              int64_t B, TpDev p) {
+  using A = typename AccOf<T>::type;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  constexpr int R = 4;
+  A* xs = reinterpret_cast<A*>(smem_raw);
+  A* ys = xs + (size_t)R * p.D1;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const A* normcol = packed + p.normcol_off;
+  const int64_t ntiles = (B + R - 1) / R;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t row0 = tile * R;
+    __syncthreads();
+    for (int i = tid; i < R * p.D1; i += 256) {
+      int r = i / p.D1, d = i - r * p.D1;
+      int64_t row = row0 + r;
+      xs[r * p.D1 + p.cpos[d]] = row < B ? to_acc(in1[row * ld1 + d]) : A(0);
+    }
+    for (int i = tid; i < R * p.Dy; i += 256) {
+      int r = i / p.Dy, d = i - r * p.Dy;
+      int64_t row = row0 + r;
+      ys[i] = row < B ? to_acc(in2[row * ld2 + d]) : A(0);
+    }
+    __syncthreads();
+    const int64_t row = row0 + wave;
+    if (row >= B) continue;  // the barriers above are reached by every wave: the tile loop is uniform per block
+    const A* x = xs + wave * p.D1;
+    const A* y = ys + wave * p.Dy;
+    for (int c3 = 0; c3 < 6; ++c3) {
+      const int l3 = c3 >> 1, D3 = 2 * l3 + 1, M = p.M[c3], K = p.K[c3];
+      if (M == 0 || K == 0) continue;
+      A* F = static_cast<A*>(Fp.p[c3]);
+      A* Gm = static_cast<A*>(Gp.p[c3]);
+      if (F) {
+        A* Fr = F + row * D3 * (int64_t)K;
+        for (int pi = 0; pi < p.npath[c3]; ++pi) {
+          const TpPath P = p.paths[p.poff[c3] + pi];
+          const int n = p.n[P.c1], D1c = 2 * P.l1 + 1;
+          const A* xc = x + p.cbase[P.c1];
+          const A* yl = y + P.l2 * P.l2;
+          for (int k = lane; k < n; k += 64) {
+            A f[5] = {0, 0, 0, 0, 0};
+            E3_GRAD_SWITCH(P.l1, P.l2, l3, G::feat(xc + k * D1c, yl, f))
+            for (int c = 0; c < D3; ++c) Fr[(int64_t)c * K + P.wrow + k] = f[c];
+          }
+        }
+      }
+      if (Gm) {
+        A* Gr = Gm + row * D3 * (int64_t)M;
+        const T* g = go + row * ldg;
+        for (int i = lane; i < D3 * M; i += 64) {
+          const int c = i / M, w = i - c * M;
+          const int oc = p.ocol[p.ocol_off[c3] + w] + c;
+          Gr[i] = to_acc(g[oc]) * normcol[oc];
+        }
+      }
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void tp_bwd_contract_kernel(const T* __restrict__ in1, int64_t ld1,
+                                                              const T* __restrict__ in2, int64_t ld2, TpPtr6 Tp,
+                                                              T* __restrict__ gin1, int64_t ldg1,
+                                                              typename AccOf<T>::type* __restrict__ gin2, int64_t ldg2,
+                                                              int64_t B, TpDev p) {
+  using A = typename AccOf<T>::type;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  constexpr int R = 4;
+  A* xs = reinterpret_cast<A*>(smem_raw);
+  A* ys = xs + (size_t)R * p.D1;
+  A* gx = ys + (size_t)R * p.Dy;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int64_t ntiles = (B + R - 1) / R;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t row0 = tile * R;
+    __syncthreads();
+    for (int i = tid; i < R * p.D1; i += 256) {
+      int r = i / p.D1, d = i - r * p.D1;
+      int64_t row = row0 + r;
+      xs[r * p.D1 + p.cpos[d]] = row < B ? to_acc(in1[row * ld1 + d]) : A(0);
+      gx[i] = 0;
+    }
+    for (int i = tid; i < R * p.Dy; i += 256) {
+      int r = i / p.Dy, d = i - r * p.Dy;
+      int64_t row = row0 + r;
+      ys[i] = row < B ? to_acc(in2[row * ld2 + d]) : A(0);
+    }
+    __syncthreads();
+    const int64_t row = row0 + wave;
+    A gy[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (row < B) {
+      const A* x = xs + wave * p.D1;
+      const A* y = ys + wave * p.Dy;
+      A* gxr = gx + wave * p.D1;
+      for (int c3 = 0; c3 < 6; ++c3) {
+        const int l3 = c3 >> 1, D3 = 2 * l3 + 1, K = p.K[c3];
+        const A* Tm = static_cast<const A*>(Tp.p[c3]);
+        if (!Tm || K == 0 || p.M[c3] == 0) continue;
+        const A* Tr = Tm + row * D3 * (int64_t)K;
+        for (int pi = 0; pi < p.npath[c3]; ++pi) {
+          const TpPath P = p.paths[p.poff[c3] + pi];
+          const int n = p.n[P.c1], D1c = 2 * P.l1 + 1;
+          const A* xc = x + p.cbase[P.c1];
+          A* gc = gxr + p.cbase[P.c1];
+          const A* yl = y + P.l2 * P.l2;
+          for (int k = lane; k < n; k += 64) {  // lane <-> channel is the same for every path of a class: no race on gc
+            A t[5] = {0, 0, 0, 0, 0}, ga[5] = {0, 0, 0, 0, 0};
+            for (int c = 0; c < D3; ++c) t[c] = Tr[(int64_t)c * K + P.wrow + k];
+            E3_GRAD_SWITCH(P.l1, P.l2, l3, G::gxy(xc + k * D1c, yl, t, ga, gy + P.l2 * P.l2))
+            for (int a = 0; a < D1c; ++a) gc[k * D1c + a] += ga[a];
+          }
+        }
+      }
+    }
+    if (gin2) {
+#pragma unroll
+      for (int q = 0; q < 9; ++q) {
+        A v = gy[q];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        gy[q] = v;
+      }
+      if (row < B && lane < p.Dy) {
+        A v = gy[0];
+#pragma unroll
+        for (int q = 1; q < 9; ++q) v = lane == q ? gy[q] : v;
+        if (ldg2 == 0) atomicAdd(&gin2[lane], v);
+        else gin2[row * ldg2 + lane] = v;
+      }
+    }
+    __syncthreads();
+    if (gin1)
+      for (int i = tid; i < R * p.D1; i += 256) {
+        int r = i / p.D1, d = i - r * p.D1;
+        if (row0 + r < B) gin1[(row0 + r) * ldg1 + d] = from_acc<T, A>(gx[r * p.D1 + p.cpos[d]]);
+      }
+  }
+}
+
+template <typename T>
+static int tp_launch_bwd_operands(const e3_tp_plan* plan, const void* in1, int64_t ld1, const void* in2, int64_t ld2,
+                                  const void* packed, const void* go, int64_t ldg, void* const F[6], void* const G[6],
+                                  int64_t B, hipStream_t s) {
+  using A = typename AccOf<T>::type;
+  const TpDev& p = plan->dev;
+  const size_t lds = (size_t)4 * (p.D1 + p.Dy) * sizeof(A);
+  if (lds > 160 * 1024) return E3_ERR_UNSUPPORTED;
+  TpPtr6 f, g;
+  for (int c = 0; c < 6; ++c) { f.p[c] = F ? F[c] : nullptr; g.p[c] = G ? G[c] : nullptr; }
+  auto k = tp_bwd_operands_kernel<T>;
+  if (lds > 64 * 1024) E3_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int grid = (int)std::min<int64_t>((B + 3) / 4, 256 * 8);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, (const T*)in1, ld1, (const T*)in2, ld2, (const A*)packed,
+                     (const T*)go, ldg, f, g, B, p);
+  E3_HIP_CHECK(hipGetLastError());
+  return E3_OK;
+}
+
+template <typename T>
+static int tp_launch_bwd_contract(const e3_tp_plan* plan, const void* in1, int64_t ld1, const void* in2, int64_t ld2,
+                                  void* const Tm[6], void* gin1, int64_t ldg1, void* gin2, int64_t ldg2, int64_t B,
+                                  hipStream_t s) {
+  using A = typename AccOf<T>::type;
+  const TpDev& p = plan->dev;
+  const size_t lds = (size_t)4 * (2 * p.D1 + p.Dy) * sizeof(A);
+  if (lds > 160 * 1024) return E3_ERR_UNSUPPORTED;
+  TpPtr6 t;
+  for (int c = 0; c < 6; ++c) t.p[c] = Tm[c];
+  auto k = tp_bwd_contract_kernel<T>;
+  if (lds > 64 * 1024) E3_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int grid = (int)std::min<int64_t>((B + 3) / 4, 256 * 8);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, (const T*)in1, ld1, (const T*)in2, ld2, t, (T*)gin1, ldg1,
+                     (A*)gin2, ldg2, B, p);
+  E3_HIP_CHECK(hipGetLastError());
   return E3_OK;
 }
 
@@ -680,6 +904,37 @@ int e3_tp_backward(const e3_tp_plan* plan, const void* in1, int64_t ld1, const v
                                                 ldg2, gw, B, s)
                          : tp_launch_bwd<double>(plan, in1, ld1, in2, ld2, packed, grad_out, ldg, grad_in1, ldg1,
                                                  grad_in2, ldg2, gw, B, s);
+}
+
+int e3_tp_backward_operands(const e3_tp_plan* plan, const void* in1, int64_t ld1, const void* in2, int64_t ld2,
+                            const void* packed, const void* grad_out, int64_t ldg, void* const features[6],
+                            void* const gout[6], int64_t B, int dtype, void* stream) {
+  if (!plan || B < 0 || (dtype != E3_F32 && dtype != E3_F64)) return E3_ERR_INVALID_ARG;
+  if (B == 0) return E3_OK;
+  if (!in1 || !in2 || !packed || (!features && !gout) || (gout && !grad_out)) return E3_ERR_INVALID_ARG;
+  if (ld1 < plan->dev.D1 || (gout && ldg < plan->dev.Dout) || (ld2 != 0 && ld2 < plan->dev.Dy)) return E3_ERR_INVALID_ARG;
+  int st = tp_ensure_device(plan);
+  if (st != E3_OK) return st;
+  hipStream_t s = (hipStream_t)stream;
+  return dtype == E3_F32
+             ? tp_launch_bwd_operands<float>(plan, in1, ld1, in2, ld2, packed, grad_out, ldg, features, gout, B, s)
+             : tp_launch_bwd_operands<double>(plan, in1, ld1, in2, ld2, packed, grad_out, ldg, features, gout, B, s);
+}
+
+int e3_tp_backward_contract(const e3_tp_plan* plan, const void* in1, int64_t ld1, const void* in2, int64_t ld2,
+                            void* const t[6], void* grad_in1, int64_t ldg1, void* grad_in2, int64_t ldg2, int64_t B,
+                            int dtype, void* stream) {
+  if (!plan || B < 0 || (dtype != E3_F32 && dtype != E3_F64)) return E3_ERR_INVALID_ARG;
+  if (B == 0) return E3_OK;
+  if (!in1 || !in2 || !t || (!grad_in1 && !grad_in2)) return E3_ERR_INVALID_ARG;
+  if (ld1 < plan->dev.D1 || (ld2 != 0 && ld2 < plan->dev.Dy)) return E3_ERR_INVALID_ARG;
+  if (grad_in1 && ldg1 < plan->dev.D1) return E3_ERR_INVALID_ARG;
+  if (grad_in2 && ((ld2 == 0) != (ldg2 == 0) || (ldg2 != 0 && ldg2 < plan->dev.Dy))) return E3_ERR_INVALID_ARG;
+  int st = tp_ensure_device(plan);
+  if (st != E3_OK) return st;
+  hipStream_t s = (hipStream_t)stream;
+  return dtype == E3_F32 ? tp_launch_bwd_contract<float>(plan, in1, ld1, in2, ld2, t, grad_in1, ldg1, grad_in2, ldg2, B, s)
+                         : tp_launch_bwd_contract<double>(plan, in1, ld1, in2, ld2, t, grad_in1, ldg1, grad_in2, ldg2, B, s);
 }
 
 const char* e3_tp_last_fused_kernel(void) { return fast_last_kernel(); }

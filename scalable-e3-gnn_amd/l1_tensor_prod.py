@@ -299,6 +299,18 @@ class L1TensorProduct(Module):
             in2 = in2.contiguous()
         ld2 = 0 if (in2.shape[0] == 1 and B != 1) else in2.stride(0)
         code = _lib.dtype_code(dtype)
+        from . import tensor_product as _tp
+        if B >= _tp._BWD_GEMM_MIN_ROWS and dtype in (torch.float32, torch.float64):
+            # large B: operands -> library GEMMs -> contract on the general plan (this operator is its lmax_sh = 1 case:
+            # same class order, weight-row order and norms, see forward_fused)
+            tpp = self._fused_plan()
+            ws6, ns6 = list(ws) + [None, None], list(ns) + [None, None]
+            with torch.cuda.device(device):
+                packed = tpp.packed(ws6, ns6, dtype, device)
+            g1, g2, gws = _tp.tp_backward(tpp, packed, in1, in2, grad_out, ws6, need_in1, need_in2,
+                                          [need_w and w is not None for w in ws6])
+            return (g1, g2.to(in2.dtype) if g2 is not None else None,
+                    {c: (gws[i].to(ws[i].dtype) if gws[i] is not None else None) for i, c in enumerate(_CLS)})
         with torch.cuda.device(device):
             plan = self._get_plan()
             wbytes = lib.e3_l1tp_backward_workspace_bytes(plan.handle(device), B, code)

@@ -207,8 +207,85 @@ def _rebuild_tpplan(in_blocks, lmax_sh, out_blocks):
     return TPPlan(in_blocks, out_blocks, lmax_sh)
 
 
+# rows per pass of the GEMM-based backward: bounds the [rows, D3, K] feature / T workspace (bytes)
+_BWD_WORKSPACE_BYTES = 1 << 30
+# below this many rows the two generic kernels of e3_tp_backward are quicker than 2 + 2 x classes launches
+_BWD_GEMM_MIN_ROWS = 512
+
+
+def tp_backward(plan: "TPPlan", packed, in1, in2, grad_out, weights, need1, need2, need_w):
+    """Gradients of ``e3_tp_forward`` -> (grad_in1 | None, grad_in2 | None (accumulation dtype), [grad_W per class | None]).
+
+    ``weights`` / ``need_w``: 6-entry lists (per output class; None = class absent).  Large B runs as
+    ``e3_tp_backward_operands`` -> per class ``grad_W += F^T G`` and ``T = G W^T`` (library GEMMs) ->
+    ``e3_tp_backward_contract``, in row chunks that bound the workspace; small B on the generic kernels of
+    ``e3_tp_backward``.  fp32 / fp64, the reference operator's gradients come from torch autograd over
+    `l1_tensor_prod.py:240-299`."""
+    lib = _lib.load()
+    B, dev, dt = in1.shape[0], in1.device, in1.dtype
+    acc = torch.float64 if dt == torch.float64 else torch.float32
+    code = _lib.dtype_code(dt)
+    bcast = in2.shape[0] == 1 and B != 1
+    ld2 = 0 if bcast else in2.stride(0)
+    g1 = torch.empty_like(in1, memory_format=torch.contiguous_format) if need1 else None
+    g2 = (torch.zeros((1, plan.in2_dim), dtype=acc, device=dev) if bcast else
+          torch.empty((B, plan.in2_dim), dtype=acc, device=dev)) if need2 else None
+    gws = [torch.zeros(w.shape, dtype=acc, device=dev) if (w is not None and nw) else None
+           for w, nw in zip(weights, need_w)]
+    if B == 0:
+        if g2 is not None:
+            g2.zero_()
+        return g1, g2, gws
+    P6 = ctypes.c_void_p * 6
+    ptr = lambda t: t.data_ptr() if t is not None else None
+    h = plan.handle(dev)
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        if B < _BWD_GEMM_MIN_ROWS:
+            _lib.check(lib.e3_tp_backward(h, in1.data_ptr(), in1.stride(0), in2.data_ptr(), ld2, packed.data_ptr(),
+                                          grad_out.data_ptr(), grad_out.stride(0), ptr(g1), g1.stride(0) if need1 else 0,
+                                          ptr(g2), 0 if (g2 is None or bcast) else g2.stride(0), P6(*map(ptr, gws)), B, code,
+                                          stream), "e3_tp_backward")
+            return g1, g2, gws
+        shapes = [tuple(w.shape) if w is not None else None for w in weights]      # (K, M) per class
+        per_row = sum((2 * (c >> 1) + 1) * (s[0] + s[1]) for c, s in enumerate(shapes) if s is not None)
+        chunk = max(256, min(B, _BWD_WORKSPACE_BYTES // (per_row * (8 if dt == torch.float64 else 4))))
+        work = torch.empty(chunk * per_row, dtype=acc, device=dev)
+        need_rows = need1 or need2
+        wacc = [w.detach().to(acc) if w is not None else None for w in weights]
+        for r0 in range(0, B, chunk):
+            r = min(chunk, B - r0)
+            Fs, Gs, off = [None] * 6, [None] * 6, 0
+            for c, s in enumerate(shapes):
+                if s is None:
+                    continue
+                d3 = 2 * (c >> 1) + 1
+                Fs[c] = work[off:off + r * d3 * s[0]].view(r * d3, s[0]); off += r * d3 * s[0]
+                Gs[c] = work[off:off + r * d3 * s[1]].view(r * d3, s[1]); off += r * d3 * s[1]
+            x, y, g = in1[r0:r0 + r], (in2 if bcast else in2[r0:r0 + r]), grad_out[r0:r0 + r]
+            want_f = [Fs[c] if gws[c] is not None else None for c in range(6)]
+            _lib.check(lib.e3_tp_backward_operands(h, x.data_ptr(), x.stride(0), y.data_ptr(), ld2, packed.data_ptr(),
+                                                   g.data_ptr(), g.stride(0), P6(*map(ptr, want_f)), P6(*map(ptr, Gs)),
+                                                   r, code, stream), "e3_tp_backward_operands")
+            for c in range(6):
+                if shapes[c] is None:
+                    continue
+                if gws[c] is not None:
+                    gws[c].addmm_(Fs[c].t(), Gs[c])
+                if need_rows:
+                    torch.mm(Gs[c], wacc[c].t(), out=Fs[c])     # T overwrites the features of this class
+            if need_rows:
+                g1c = g1[r0:r0 + r] if need1 else None
+                g2c = (g2 if bcast else g2[r0:r0 + r]) if need2 else None
+                _lib.check(lib.e3_tp_backward_contract(h, x.data_ptr(), x.stride(0), y.data_ptr(), ld2,
+                                                       P6(*map(ptr, Fs)), ptr(g1c), g1c.stride(0) if need1 else 0,
+                                                       ptr(g2c), 0 if (g2c is None or bcast) else g2c.stride(0), r, code,
+                                                       stream), "e3_tp_backward_contract")
+    return g1, g2, gws
+
+
 class _SHTPFunction(torch.autograd.Function):
-    """autograd bridge: forward = e3_tp_forward, backward = e3_tp_backward (fp32 / fp64)."""
+    """autograd bridge: forward = e3_tp_forward, backward = ``tp_backward`` (fp32 / fp64)."""
 
     @staticmethod
     def forward(ctx, mod, in1, in2, *weights):
@@ -221,43 +298,18 @@ class _SHTPFunction(torch.autograd.Function):
     def backward(ctx, grad_out):
         mod = ctx.mod
         in1, in2, *weights = ctx.saved_tensors
-        lib = _lib.load()
-        B = in1.shape[0]
         if grad_out.stride(-1) != 1 or grad_out.dtype != in1.dtype:
             grad_out = grad_out.to(in1.dtype).contiguous()
-        acc = torch.float64 if in1.dtype == torch.float64 else torch.float32
-        need1, need2 = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
-        bcast = in2.shape[0] == 1 and B != 1
-        g1 = torch.empty_like(in1) if need1 else None
-        g2 = (torch.zeros((1, mod.in2_dim), dtype=acc, device=in1.device) if bcast else
-              torch.empty((B, mod.in2_dim), dtype=acc, device=in1.device)) if need2 else None
-        present = [c for c in CLASSES if hasattr(mod, "weights_" + c)]
-        gws, ptrs, wi = [], [], 0
-        for c in CLASSES:
-            if c in present:
-                need = ctx.needs_input_grad[3 + wi]
-                gw = torch.zeros(weights[wi].shape, dtype=acc, device=in1.device) if need else None
-                gws.append(gw)
-                ptrs.append(gw.data_ptr() if gw is not None else None)
-                wi += 1
-            else:
-                ptrs.append(None)
-        if B > 0:
-            with torch.cuda.device(in1.device):
-                packed = mod._packed_weights(in1.dtype, in1.device)
-                stream = torch.cuda.current_stream(in1.device).cuda_stream
-                _lib.check(lib.e3_tp_backward(mod._plan.handle(in1.device), in1.data_ptr(), in1.stride(0), in2.data_ptr(),
-                                              0 if bcast else in2.stride(0), packed.data_ptr(), grad_out.data_ptr(),
-                                              grad_out.stride(0), g1.data_ptr() if g1 is not None else None,
-                                              in1.stride(0) if g1 is not None else 0,
-                                              g2.data_ptr() if g2 is not None else None,
-                                              0 if (g2 is None or bcast) else g2.stride(0),
-                                              (ctypes.c_void_p * 6)(*ptrs), B, _lib.dtype_code(in1.dtype), stream),
-                           "e3_tp_backward")
-        elif g1 is not None or g2 is not None:
-            g2 = torch.zeros_like(g2) if g2 is not None else None
+        present = [hasattr(mod, "weights_" + c) for c in CLASSES]
+        it, ni = iter(weights), iter(ctx.needs_input_grad[3:])
+        ws = [next(it) if pr else None for pr in present]
+        nw = [next(ni) if pr else False for pr in present]
+        with torch.cuda.device(in1.device):
+            packed = mod._packed_weights(in1.dtype, in1.device)
+        g1, g2, gws = tp_backward(mod._plan, packed, in1, in2, grad_out, ws, ctx.needs_input_grad[1],
+                                  ctx.needs_input_grad[2], nw)
         out = [None, g1, g2.to(in2.dtype) if g2 is not None else None]
-        out += [gw.to(w.dtype) if gw is not None else None for gw, w in zip(gws, weights)]
+        out += [gw.to(w.dtype) if gw is not None else None for gw, w, pr in zip(gws, ws, present) if pr]
         return tuple(out)
 
 

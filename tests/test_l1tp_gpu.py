@@ -60,8 +60,13 @@ def test_forward_matches_reference_golden(name, kernel):
     close(out, z["out"], TOL[c["dtype"]], name)
 
 
+@pytest.mark.parametrize("path", ["kernels", "gemm"])
 @pytest.mark.parametrize("name", sorted(META["cases"]))
-def test_backward_matches_reference_golden(name):
+def test_backward_matches_reference_golden(name, path, monkeypatch):
+    """path: the operator's own 16-row kernels (small B) / operands -> library GEMMs -> contract on the general plan
+    (`tensor_product.tp_backward`, what large B runs)."""
+    from scalable_e3_gnn_amd import tensor_product as TPM
+    monkeypatch.setattr(TPM, "_BWD_GEMM_MIN_ROWS", 0 if path == "gemm" else 1 << 30)
     c = META["cases"][name]
     z = load_case(name)
     mod = module_from_case(c, z)

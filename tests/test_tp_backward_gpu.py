@@ -27,7 +27,15 @@ def oracle_grads(mod, in1_irreps, out_irreps, lmax, x, y, gout, dtype):
     ("8x0e+8x1o", "8x0e+8x1o", 1, "float64", 19, True),
     ("32x0e+32x1o+32x2e", "32x0e+64x0e+32x1o+32x2e", 2, "float32", 70, False),   # forward on the MFMA kernel
 ])
-def test_backward_vs_oracle_autograd(in1, out, lmax, dtype, B, bcast):
+@pytest.mark.parametrize("path", ["generic", "gemm", "gemm_chunked"])
+def test_backward_vs_oracle_autograd(in1, out, lmax, dtype, B, bcast, path, monkeypatch):
+    """Both backward paths of `tensor_product.tp_backward`: the two generic kernels (small B) and operands -> GEMMs ->
+    contract (large B; `gemm_chunked` shrinks the workspace so that the row loop takes several passes)."""
+    from scalable_e3_gnn_amd import tensor_product as TPM
+    monkeypatch.setattr(TPM, "_BWD_GEMM_MIN_ROWS", 1 << 30 if path == "generic" else 0)
+    if path == "gemm_chunked":
+        monkeypatch.setattr(TPM, "_BWD_WORKSPACE_BYTES", 1 << 16)
+        B = B * 9
     dt = getattr(torch, dtype)
     torch.manual_seed(0)
     mod = SHTensorProduct(in1, out, lmax).to(dt).to(DEV)
