@@ -487,9 +487,74 @@ static int tp_launch_bwd(const e3_tp_plan* plan, const void* in1, int64_t ld1, c
 //   contract:  grad_in1[b,k,a] = sum_paths sum_{bq,c} C y[b,bq] T[b,c,wrow+k]   grad_in2[b,bq] = sum_paths sum_{k,a,c} C x T
 // One wave owns one row; lanes run over the channels k of a path, so F / T accesses are contiguous runs.
 // ---------------------------------------------------------------------------------------------------
+// one path, RW rows of one wave: features of channel k = lane, lane + 64, ... (everything indexed at compile time)
+template <typename G, typename A, int RW>
+__device__ __forceinline__ void tp_bwd_feat_path(const A* xb, int ldx, const A* yb, int ldy, int n, int lane, int nrow,
+                                                 A* F, int K) {
+  if constexpr (G::ok) {
+    for (int k = lane; k < n; k += 64) {
+#pragma unroll
+      for (int q = 0; q < RW; ++q) {
+        if (q < nrow) {
+          A f[G::D3];
+          G::feat(xb + q * ldx + k * G::D1, yb + q * ldy + G::D2 / 2 * (G::D2 / 2), f);
+          A* Fr = F + (int64_t)q * G::D3 * K + k;
+#pragma unroll
+          for (int c = 0; c < G::D3; ++c) Fr[(int64_t)c * K] = f[c];
+        }
+      }
+    }
+  }
+}
+
+template <typename G, typename A, int RW>
+__device__ __forceinline__ void tp_bwd_contract_path(const A* xb, A* gxb, int ldx, const A* yb, int ldy, int n, int lane,
+                                                     const A* ts, int K, A (&gy)[RW][9]) {
+  if constexpr (G::ok) {
+    constexpr int L2 = G::D2 / 2;
+    for (int k = lane; k < n; k += 64) {
+#pragma unroll
+      for (int q = 0; q < RW; ++q) {
+        A t[G::D3], ga[G::D1], gq[G::D2];
+#pragma unroll
+        for (int c = 0; c < G::D3; ++c) t[c] = ts[(q * G::D3 + c) * K + k];
+#pragma unroll
+        for (int a = 0; a < G::D1; ++a) ga[a] = 0;
+#pragma unroll
+        for (int j = 0; j < G::D2; ++j) gq[j] = 0;
+        G::gxy(xb + q * ldx + k * G::D1, yb + q * ldy + L2 * L2, t, ga, gq);
+        A* gc = gxb + q * ldx + k * G::D1;
+#pragma unroll
+        for (int a = 0; a < G::D1; ++a) gc[a] += ga[a];
+#pragma unroll
+        for (int j = 0; j < G::D2; ++j) gy[q][L2 * L2 + j] += gq[j];
+      }
+    }
+  }
+}
+
 struct TpPtr6 { void* p[6]; };
 
-template <typename T>
+// stage the rows of one block: x in class order, y; rows past B read as zero
+template <typename T, typename A>
+__device__ __forceinline__ void tp_bwd_stage_xy(const T* in1, int64_t ld1, const T* in2, int64_t ld2, int64_t row0, int R,
+                                                int64_t B, const TpDev& p, A* xs, A* ys) {
+  const int tid = threadIdx.x;
+  for (int i = tid; i < R * p.D1; i += 256) {
+    int r = i / p.D1, d = i - r * p.D1;
+    int64_t row = row0 + r;
+    xs[r * p.D1 + p.cpos[d]] = row < B ? to_acc(in1[row * ld1 + d]) : A(0);
+  }
+  for (int i = tid; i < R * p.Dy; i += 256) {
+    int r = i / p.Dy, d = i - r * p.Dy;
+    int64_t row = row0 + r;
+    ys[i] = row < B ? to_acc(in2[row * ld2 + d]) : A(0);
+  }
+}
+
+// RW rows per wave (4 waves, R = 4 RW rows per block): the RW rows of a wave go through every path together, so their
+// loads / stores are in flight at the same time
+template <typename T, int RW>
 __global__ __launch_bounds__(256) void tp_bwd_operands_kernel(const T* __restrict__ in1, int64_t ld1,
                                                               const T* __restrict__ in2, int64_t ld2,
                                                               const typename AccOf<T>::type* __restrict__ packed,
@@ -497,63 +562,50 @@ __global__ __launch_bounds__(256) void tp_bwd_operands_kernel(const T* __restric
                                                               int64_t B, TpDev p) {
   using A = typename AccOf<T>::type;
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  constexpr int R = 4;
+  constexpr int R = 4 * RW;
   A* xs = reinterpret_cast<A*>(smem_raw);
   A* ys = xs + (size_t)R * p.D1;
+  A* gs = ys + (size_t)R * p.Dy;  // grad_out * norm, original column order (staged with x and y: one round of loads per tile)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const A* normcol = packed + p.normcol_off;
   const int64_t ntiles = (B + R - 1) / R;
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {  // uniform trip count per block: barriers are safe
     const int64_t row0 = tile * R;
     __syncthreads();
-    for (int i = tid; i < R * p.D1; i += 256) {
-      int r = i / p.D1, d = i - r * p.D1;
-      int64_t row = row0 + r;
-      xs[r * p.D1 + p.cpos[d]] = row < B ? to_acc(in1[row * ld1 + d]) : A(0);
-    }
-    for (int i = tid; i < R * p.Dy; i += 256) {
-      int r = i / p.Dy, d = i - r * p.Dy;
-      int64_t row = row0 + r;
-      ys[i] = row < B ? to_acc(in2[row * ld2 + d]) : A(0);
-    }
+    if (go) tp_bwd_stage<T, A>(in1, ld1, in2, ld2, go, ldg, normcol, row0, R, B, p, xs, ys, gs);
+    else tp_bwd_stage_xy<T, A>(in1, ld1, in2, ld2, row0, R, B, p, xs, ys);
     __syncthreads();
-    const int64_t row = row0 + wave;
-    if (row >= B) continue;  // the barriers above are reached by every wave: the tile loop is uniform per block
-    const A* x = xs + wave * p.D1;
-    const A* y = ys + wave * p.Dy;
+    const int64_t wrow0 = row0 + wave * RW;
     for (int c3 = 0; c3 < 6; ++c3) {
       const int l3 = c3 >> 1, D3 = 2 * l3 + 1, M = p.M[c3], K = p.K[c3];
       if (M == 0 || K == 0) continue;
       A* F = static_cast<A*>(Fp.p[c3]);
       A* Gm = static_cast<A*>(Gp.p[c3]);
       if (F) {
-        A* Fr = F + row * D3 * (int64_t)K;
         for (int pi = 0; pi < p.npath[c3]; ++pi) {
           const TpPath P = p.paths[p.poff[c3] + pi];
-          const int n = p.n[P.c1], D1c = 2 * P.l1 + 1;
-          const A* xc = x + p.cbase[P.c1];
-          const A* yl = y + P.l2 * P.l2;
-          for (int k = lane; k < n; k += 64) {
-            A f[5] = {0, 0, 0, 0, 0};
-            E3_GRAD_SWITCH(P.l1, P.l2, l3, G::feat(xc + k * D1c, yl, f))
-            for (int c = 0; c < D3; ++c) Fr[(int64_t)c * K + P.wrow + k] = f[c];
-          }
+          const int n = p.n[P.c1];
+          const A* xb = xs + wave * RW * p.D1 + p.cbase[P.c1];
+          const A* yb = ys + wave * RW * p.Dy;
+          const int nrow = B - wrow0 < RW ? (int)(B - wrow0) : RW;  // <= 0 for a wave past the end
+          E3_GRAD_SWITCH(P.l1, P.l2, l3, (tp_bwd_feat_path<G, A, RW>(xb, p.D1, yb, p.Dy, n, lane, nrow,
+                                                                     F + wrow0 * G::D3 * (int64_t)K + P.wrow, K)))
         }
       }
       if (Gm) {
-        A* Gr = Gm + row * D3 * (int64_t)M;
-        const T* g = go + row * ldg;
         for (int i = lane; i < D3 * M; i += 64) {
           const int c = i / M, w = i - c * M;
           const int oc = p.ocol[p.ocol_off[c3] + w] + c;
-          Gr[i] = to_acc(g[oc]) * normcol[oc];
+#pragma unroll
+          for (int q = 0; q < RW; ++q)
+            if (wrow0 + q < B) Gm[(wrow0 + q) * D3 * (int64_t)M + i] = gs[(wave * RW + q) * p.Dout + oc];
         }
       }
     }
   }
 }
 
-template <typename T>
+template <typename T, int RW>
 __global__ __launch_bounds__(256) void tp_bwd_contract_kernel(const T* __restrict__ in1, int64_t ld1,
                                                               const T* __restrict__ in2, int64_t ld2, TpPtr6 Tp,
                                                               T* __restrict__ gin1, int64_t ldg1,
@@ -561,93 +613,129 @@ __global__ __launch_bounds__(256) void tp_bwd_contract_kernel(const T* __restric
                                                               int64_t B, TpDev p) {
   using A = typename AccOf<T>::type;
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  constexpr int R = 4;
+  constexpr int R = 4 * RW;
   A* xs = reinterpret_cast<A*>(smem_raw);
   A* ys = xs + (size_t)R * p.D1;
   A* gx = ys + (size_t)R * p.Dy;
+  A* ts = gx + (size_t)R * p.D1;  // the R rows of T, class after class: [c3][row][c][K] (a flat copy of each class's rows)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int64_t ntiles = (B + R - 1) / R;
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t row0 = tile * R;
+    const int nr = B - row0 < R ? (int)(B - row0) : R;
     __syncthreads();
-    for (int i = tid; i < R * p.D1; i += 256) {
-      int r = i / p.D1, d = i - r * p.D1;
-      int64_t row = row0 + r;
-      xs[r * p.D1 + p.cpos[d]] = row < B ? to_acc(in1[row * ld1 + d]) : A(0);
-      gx[i] = 0;
-    }
-    for (int i = tid; i < R * p.Dy; i += 256) {
-      int r = i / p.Dy, d = i - r * p.Dy;
-      int64_t row = row0 + r;
-      ys[i] = row < B ? to_acc(in2[row * ld2 + d]) : A(0);
-    }
-    __syncthreads();
-    const int64_t row = row0 + wave;
-    A gy[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (row < B) {
-      const A* x = xs + wave * p.D1;
-      const A* y = ys + wave * p.Dy;
-      A* gxr = gx + wave * p.D1;
+    {  // every load of the tile is issued here, back to back; the path loop below only touches LDS
+      A* td = ts;
       for (int c3 = 0; c3 < 6; ++c3) {
-        const int l3 = c3 >> 1, D3 = 2 * l3 + 1, K = p.K[c3];
         const A* Tm = static_cast<const A*>(Tp.p[c3]);
-        if (!Tm || K == 0 || p.M[c3] == 0) continue;
-        const A* Tr = Tm + row * D3 * (int64_t)K;
-        for (int pi = 0; pi < p.npath[c3]; ++pi) {
-          const TpPath P = p.paths[p.poff[c3] + pi];
-          const int n = p.n[P.c1], D1c = 2 * P.l1 + 1;
-          const A* xc = x + p.cbase[P.c1];
-          A* gc = gxr + p.cbase[P.c1];
-          const A* yl = y + P.l2 * P.l2;
-          for (int k = lane; k < n; k += 64) {  // lane <-> channel is the same for every path of a class: no race on gc
-            A t[5] = {0, 0, 0, 0, 0}, ga[5] = {0, 0, 0, 0, 0};
-            for (int c = 0; c < D3; ++c) t[c] = Tr[(int64_t)c * K + P.wrow + k];
-            E3_GRAD_SWITCH(P.l1, P.l2, l3, G::gxy(xc + k * D1c, yl, t, ga, gy + P.l2 * P.l2))
-            for (int a = 0; a < D1c; ++a) gc[k * D1c + a] += ga[a];
-          }
-        }
+        const int per = (2 * (c3 >> 1) + 1) * p.K[c3];
+        if (!Tm || per == 0 || p.M[c3] == 0) continue;
+        const A* src = Tm + row0 * per;
+        for (int i = tid; i < nr * per; i += 256) td[i] = src[i];
+        td += R * per;
       }
+    }
+    tp_bwd_stage_xy<T, A>(in1, ld1, in2, ld2, row0, R, B, p, xs, ys);
+    for (int i = tid; i < R * p.D1; i += 256) gx[i] = 0;
+    __syncthreads();
+    const int64_t wrow0 = row0 + wave * RW;
+    A gy[RW][9];
+#pragma unroll
+    for (int q = 0; q < RW; ++q)
+#pragma unroll
+      for (int j = 0; j < 9; ++j) gy[q][j] = 0;
+    const A* tc = ts;
+    for (int c3 = 0; c3 < 6; ++c3) {
+      const int l3 = c3 >> 1, D3 = 2 * l3 + 1, K = p.K[c3];
+      if (!Tp.p[c3] || K == 0 || p.M[c3] == 0) continue;
+      for (int pi = 0; pi < p.npath[c3]; ++pi) {
+        const TpPath P = p.paths[p.poff[c3] + pi];
+        // lane <-> channel is the same for every path of a class: no race on gx.  Rows past B hold stale LDS: their
+        // results stay in LDS / registers and are dropped
+        E3_GRAD_SWITCH(P.l1, P.l2, l3, (tp_bwd_contract_path<G, A, RW>(
+                                           xs + wave * RW * p.D1 + p.cbase[P.c1], gx + wave * RW * p.D1 + p.cbase[P.c1],
+                                           p.D1, ys + wave * RW * p.Dy, p.Dy, p.n[P.c1], lane,
+                                           tc + wave * RW * G::D3 * K + P.wrow, K, gy)))
+      }
+      tc += R * D3 * K;
     }
     if (gin2) {
 #pragma unroll
-      for (int q = 0; q < 9; ++q) {
-        A v = gy[q];
+      for (int q = 0; q < RW; ++q) {
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        gy[q] = v;
-      }
-      if (row < B && lane < p.Dy) {
-        A v = gy[0];
+        for (int j = 0; j < 9; ++j) {
+          A v = gy[q][j];
 #pragma unroll
-        for (int q = 1; q < 9; ++q) v = lane == q ? gy[q] : v;
-        if (ldg2 == 0) atomicAdd(&gin2[lane], v);
-        else gin2[row * ldg2 + lane] = v;
+          for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+          gy[q][j] = v;
+        }
+        if (wrow0 + q < B && lane < p.Dy) {
+          A v = gy[q][0];
+#pragma unroll
+          for (int j = 1; j < 9; ++j) v = lane == j ? gy[q][j] : v;
+          if (ldg2 == 0) atomicAdd(&gin2[lane], v);
+          else gin2[(wrow0 + q) * ldg2 + lane] = v;
+        }
       }
     }
     __syncthreads();
     if (gin1)
-      for (int i = tid; i < R * p.D1; i += 256) {
+      for (int i = tid; i < nr * p.D1; i += 256) {
         int r = i / p.D1, d = i - r * p.D1;
-        if (row0 + r < B) gin1[(row0 + r) * ldg1 + d] = from_acc<T, A>(gx[r * p.D1 + p.cpos[d]]);
+        gin1[(row0 + r) * ldg1 + d] = from_acc<T, A>(gx[r * p.D1 + p.cpos[d]]);
       }
   }
+}
+
+template <typename T, int RW>
+static int tp_launch_bwd_operands_rw(const e3_tp_plan* plan, const void* in1, int64_t ld1, const void* in2, int64_t ld2,
+                                     const void* packed, const void* go, int64_t ldg, const TpPtr6& f, const TpPtr6& g,
+                                     int64_t B, hipStream_t s) {
+  using A = typename AccOf<T>::type;
+  const TpDev& p = plan->dev;
+  constexpr int R = 4 * RW;
+  const size_t lds = (size_t)R * (p.D1 + p.Dy + p.Dout) * sizeof(A);
+  if (lds > 160 * 1024) return E3_ERR_UNSUPPORTED;
+  auto k = tp_bwd_operands_kernel<T, RW>;
+  if (lds > 64 * 1024) E3_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int grid = (int)std::min<int64_t>((B + R - 1) / R, 256 * 8);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, (const T*)in1, ld1, (const T*)in2, ld2, (const A*)packed,
+                     (const T*)go, ldg, f, g, B, p);
+  E3_HIP_CHECK(hipGetLastError());
+  return E3_OK;
 }
 
 template <typename T>
 static int tp_launch_bwd_operands(const e3_tp_plan* plan, const void* in1, int64_t ld1, const void* in2, int64_t ld2,
                                   const void* packed, const void* go, int64_t ldg, void* const F[6], void* const G[6],
                                   int64_t B, hipStream_t s) {
-  using A = typename AccOf<T>::type;
-  const TpDev& p = plan->dev;
-  const size_t lds = (size_t)4 * (p.D1 + p.Dy) * sizeof(A);
-  if (lds > 160 * 1024) return E3_ERR_UNSUPPORTED;
   TpPtr6 f, g;
   for (int c = 0; c < 6; ++c) { f.p[c] = F ? F[c] : nullptr; g.p[c] = G ? G[c] : nullptr; }
-  auto k = tp_bwd_operands_kernel<T>;
+  return tp_launch_bwd_operands_rw<T, 2>(plan, in1, ld1, in2, ld2, packed, go, ldg, f, g, B, s);
+}
+
+template <typename A>
+static size_t tp_bwd_contract_lds(const TpDev& p, int R) {
+  size_t trow = 0;
+  for (int c = 0; c < 6; ++c)
+    if (p.M[c] > 0) trow += (size_t)(2 * (c >> 1) + 1) * p.K[c];
+  return (size_t)R * (2 * p.D1 + p.Dy + trow) * sizeof(A);
+}
+
+template <typename T, int RW>
+static int tp_launch_bwd_contract_rw(const e3_tp_plan* plan, const void* in1, int64_t ld1, const void* in2, int64_t ld2,
+                                     const TpPtr6& t, void* gin1, int64_t ldg1, void* gin2, int64_t ldg2, int64_t B,
+                                     hipStream_t s) {
+  using A = typename AccOf<T>::type;
+  const TpDev& p = plan->dev;
+  constexpr int R = 4 * RW;
+  const size_t lds = tp_bwd_contract_lds<A>(p, R);
+  if (lds > 160 * 1024) return E3_ERR_UNSUPPORTED;
+  auto k = tp_bwd_contract_kernel<T, RW>;
   if (lds > 64 * 1024) E3_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const int grid = (int)std::min<int64_t>((B + 3) / 4, 256 * 8);
-  hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, (const T*)in1, ld1, (const T*)in2, ld2, (const A*)packed,
-                     (const T*)go, ldg, f, g, B, p);
+  const int grid = (int)std::min<int64_t>((B + R - 1) / R, 256 * 8);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, (const T*)in1, ld1, (const T*)in2, ld2, t, (T*)gin1, ldg1,
+                     (A*)gin2, ldg2, B, p);
   E3_HIP_CHECK(hipGetLastError());
   return E3_OK;
 }
@@ -657,18 +745,14 @@ static int tp_launch_bwd_contract(const e3_tp_plan* plan, const void* in1, int64
                                   void* const Tm[6], void* gin1, int64_t ldg1, void* gin2, int64_t ldg2, int64_t B,
                                   hipStream_t s) {
   using A = typename AccOf<T>::type;
-  const TpDev& p = plan->dev;
-  const size_t lds = (size_t)4 * (2 * p.D1 + p.Dy) * sizeof(A);
-  if (lds > 160 * 1024) return E3_ERR_UNSUPPORTED;
   TpPtr6 t;
-  for (int c = 0; c < 6; ++c) t.p[c] = Tm[c];
-  auto k = tp_bwd_contract_kernel<T>;
-  if (lds > 64 * 1024) E3_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const int grid = (int)std::min<int64_t>((B + 3) / 4, 256 * 8);
-  hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, (const T*)in1, ld1, (const T*)in2, ld2, t, (T*)gin1, ldg1,
-                     (A*)gin2, ldg2, B, p);
-  E3_HIP_CHECK(hipGetLastError());
-  return E3_OK;
+  for (int c = 0; c < 6; ++c) t.p[c] = (plan->dev.M[c] > 0 && plan->dev.K[c] > 0) ? Tm[c] : nullptr;
+  for (int c = 0; c < 6; ++c)
+    if (plan->dev.M[c] > 0 && plan->dev.K[c] > 0 && !Tm[c]) return E3_ERR_INVALID_ARG;  // every class with weights has a T
+  // rows per block by LDS budget: 4 blocks per CU (40 KB each) if possible
+  if (tp_bwd_contract_lds<A>(plan->dev, 8) <= 40 * 1024)
+    return tp_launch_bwd_contract_rw<T, 2>(plan, in1, ld1, in2, ld2, t, gin1, ldg1, gin2, ldg2, B, s);
+  return tp_launch_bwd_contract_rw<T, 1>(plan, in1, ld1, in2, ld2, t, gin1, ldg1, gin2, ldg2, B, s);
 }
 
 }  // namespace e3

@@ -213,6 +213,25 @@ _BWD_WORKSPACE_BYTES = 1 << 30
 _BWD_GEMM_MIN_ROWS = 512
 
 
+_WGRAD_SLAB = 4096
+
+
+def _wgrad_accumulate(gw, F, G):
+    """gw [K, M] += F^T G with F [R, K], G [R, M], R >> K, M: the reduction runs over R, so one GEMM has K M / tile
+    workgroups and a very long loop; slabs of ``_WGRAD_SLAB`` rows as one batched GEMM fill the device, the per-slab
+    [K, M] results are summed afterwards."""
+    R = F.shape[0]
+    nb = R // _WGRAD_SLAB
+    if nb >= 4:
+        body = nb * _WGRAD_SLAB
+        part = torch.bmm(F[:body].view(nb, _WGRAD_SLAB, -1).transpose(1, 2), G[:body].view(nb, _WGRAD_SLAB, -1))
+        gw.add_(part.sum(0))
+        if body < R:
+            gw.addmm_(F[body:].t(), G[body:])
+    else:
+        gw.addmm_(F.t(), G)
+
+
 def tp_backward(plan: "TPPlan", packed, in1, in2, grad_out, weights, need1, need2, need_w):
     """Gradients of ``e3_tp_forward`` -> (grad_in1 | None, grad_in2 | None (accumulation dtype), [grad_W per class | None]).
 
@@ -271,7 +290,7 @@ def tp_backward(plan: "TPPlan", packed, in1, in2, grad_out, weights, need1, need
                 if shapes[c] is None:
                     continue
                 if gws[c] is not None:
-                    gws[c].addmm_(Fs[c].t(), Gs[c])
+                    _wgrad_accumulate(gws[c], Fs[c], Gs[c])
                 if need_rows:
                     torch.mm(Gs[c], wacc[c].t(), out=Fs[c])     # T overwrites the features of this class
             if need_rows:

@@ -5,8 +5,9 @@
       4 layers, H = 32: energies + forces (-dE/dpos) + dE/dparam = one training step on energies with forces predicted;
   (b) BASELINE.json configs[1]: 100 k particles, l_max = 1, 4 layers, H = 32: forward + backward of sum(out^2) w.r.t. every
       parameter.
-The fast fused kernels are inference kernels; a call that needs a gradient runs the differentiable chain on the generic FMA
-kernels (SEGNNLayer warns once and names the reason).  HIP-event times, ms per step after a warm-up.
+The one-launch fused kernels are inference kernels; a call that needs a gradient runs the differentiable chain (SEGNNLayer
+warns once and names the reason): per-product forward kernels (MFMA where the shape has one) with [E, width] tensors
+materialised, and the operands -> library GEMMs -> contract backward of tensor_product.tp_backward.  HIP-event times, ms per step after a warm-up.
 """
 import json, math, os, sys, warnings
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -62,8 +63,8 @@ def fwd_a():
 model.eval(); t_inf = timed(fwd_a); model.train()
 t_train = timed(step_a)
 out["qm9_128mol_lmax2"] = {"atoms": N, "forward_inference_ms": t_inf, "energy_forces_param_grads_ms": t_train,
-                           "note": "inference = fused MFMA kernels; training step = differentiable chain on the generic FMA kernels "
-                                   "(forward with autograd graph, -dE/dpos, dE/dparam)"}
+                           "note": "inference = fused MFMA kernels; training step = differentiable chain, backward = operands -> GEMMs -> "
+                                   "contract (forward with autograd graph, -dE/dpos, dE/dparam)"}
 print(json.dumps(out["qm9_128mol_lmax2"]), flush=True)
 
 # ---- (b) 100 k particles, l_max = 1 ----
@@ -95,7 +96,7 @@ t_train = timed(step_b)
 out["particles_100k_lmax1"] = {"particles": n, "edges": gr.num_edges, "forward_inference_ms": t_inf,
                                "forward_backward_ms": t_train,
                                "note": "graph build excluded; inference = fused MFMA kernels; forward + backward = differentiable "
-                                       "chain on the generic FMA kernels ([E, width] tensors materialised)"}
+                                       "chain ([E, width] tensors materialised), backward = operands -> GEMMs -> contract"}
 print(json.dumps(out["particles_100k_lmax1"]), flush=True)
 if len(sys.argv) > 1:
     json.dump(out, open(sys.argv[1], "w"), indent=1)
