@@ -256,6 +256,13 @@ int e3_add_pow2_scale(const float* h, const float* u, float* out, int64_t n, int
 int e3_tp_forward_fused(const e3_tp_plan* plan, const e3_tp_segment* segs, int nseg,
                         const void* in2, int64_t ld_in2, const void* packed, void* out, int64_t ld_out,
                         int64_t B, int dtype, int gate, const float* in_scale, void* stream);
+/* e3_tp_forward_fused with two epilogue extras, so that a layer's residual update and the next operand scale cost no pass
+ * of their own:  out = (gated) product + residual   (residual: [B, width of out], storage dtype, null = none), and
+ * out_scale4 (null = none) receives what e3_pow2_scale(out, target_log2) would: {s, 1/s, bits of max |out|, -}. */
+int e3_tp_forward_fused_epilogue(const e3_tp_plan* plan, const e3_tp_segment* segs, int nseg, const void* in2,
+                                 int64_t ld_in2, const void* packed, void* out, int64_t ld_out, int64_t B, int dtype,
+                                 int gate, const float* in_scale, const void* residual, int64_t ld_residual,
+                                 float* out_scale4, int target_log2, void* stream);
 /* Gradients of e3_tp_forward (fp32 / fp64; the reference operator relies on torch autograd, l1_tensor_prod.py:240-299).
  * `packed` = the buffer e3_tp_pack_weights wrote for this dtype.  Any of grad_in1 [B, in1_dim] (storage dtype),
  * grad_in2 [B, in2_dim] (ACCUMULATION dtype: fp32 for E3_F32, fp64 for E3_F64; with broadcast in2, ld_in2 == 0, pass

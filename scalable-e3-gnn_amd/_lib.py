@@ -90,6 +90,8 @@ SIGNATURES = {
                                         c_void_p, c_int64, c_int, c_void_p]),
     "e3_tp_backward_contract": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
                                         c_int64, c_int64, c_int, c_void_p]),
+    "e3_tp_forward_fused_epilogue": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
+                                             c_int64, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p]),
     "e3_tp_fused_supported": (c_int, [c_void_p, c_int]),
     "e3_tp_last_fused_kernel": (ctypes.c_char_p, []),
     "e3_tp_forward_fused_scatter": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,

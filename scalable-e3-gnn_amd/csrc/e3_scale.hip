@@ -76,6 +76,12 @@ __global__ __launch_bounds__(256) void add_absmax_kernel(const float4* __restric
   if ((threadIdx.x & 63) == 0 && m > 0.f && m < INFINITY) atomicMax(bits, __builtin_bit_cast(uint32_t, m));
 }
 
+int scale_finalize(float* out4, int target_log2, hipStream_t s) {
+  hipLaunchKernelGGL(scale_finalize_kernel, dim3(1), dim3(1), 0, s, out4, target_log2);
+  E3_HIP_CHECK(hipGetLastError());
+  return E3_OK;
+}
+
 }  // namespace e3
 
 using namespace e3;

@@ -957,6 +957,27 @@ int e3_tp_forward_fused(const e3_tp_plan* plan, const e3_tp_segment* segs, int n
                       out, ldo, B, gate, dtype, plan->dev.ocol, in_scale, (hipStream_t)stream);
 }
 
+int e3_tp_forward_fused_epilogue(const e3_tp_plan* plan, const e3_tp_segment* segs, int nseg, const void* in2,
+                                 int64_t ld2, const void* packed, void* out, int64_t ldo, int64_t B, int dtype, int gate,
+                                 const float* in_scale, const void* residual, int64_t ld_residual, float* out_scale4,
+                                 int target_log2, void* stream) {
+  if (!plan || !segs || B < 0 || (residual && ld_residual <= 0)) return E3_ERR_INVALID_ARG;
+  if (out_scale4 && (target_log2 < -20 || target_log2 > 14)) return E3_ERR_INVALID_ARG;
+  if ((dtype != E3_F32 && dtype != E3_BF16) || !plan->fast.usable || ld2 == 0) return E3_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  if (out_scale4) E3_HIP_CHECK(hipMemsetAsync(out_scale4, 0, 16, s));
+  if (B > 0) {
+    if (!in2 || !packed || !out || ld2 < plan->dev.Dy) return E3_ERR_INVALID_ARG;
+    int st = tp_ensure_device(plan);
+    if (st != E3_OK) return st;
+    st = fast_forward(&plan->fast, segs, nseg, plan->dev.D1, in2, ld2, (const char*)packed + fast_section_offset(plan), out,
+                      ldo, B, gate, dtype, plan->dev.ocol, in_scale, s, nullptr, residual, ld_residual,
+                      out_scale4 ? reinterpret_cast<uint32_t*>(out_scale4) + 2 : nullptr);
+    if (st != E3_OK) return st;
+  }
+  return out_scale4 ? scale_finalize(out_scale4, target_log2, s) : E3_OK;
+}
+
 int e3_tp_forward_fused_scatter(const e3_tp_plan* plan, const e3_tp_segment* segs, int nseg, const void* in2,
                                 int64_t ld2, const void* packed, const int32_t* row_node, void* out_nodes,
                                 int64_t ldo, int64_t B, int dtype, int gate, const float* in_scale, void* stream) {

@@ -52,7 +52,10 @@ int fast_pack(const TpFast* F, const void* const w[6], const void* const n[6], i
               const int32_t* ocol_tab, hipStream_t s);
 int fast_forward(const TpFast* F, const e3_tp_segment* segs, int nseg, int D1, const void* in2, int64_t ld2,
                  const void* packed, void* out, int64_t ldo, int64_t B, int gate, int dtype, const int32_t* ocol_tab,
-                 const float* in_scale, hipStream_t s, const int32_t* scatter = nullptr);
+                 const float* in_scale, hipStream_t s, const int32_t* scatter = nullptr, const void* residual = nullptr,
+                 int64_t ldr = 0, uint32_t* amax = nullptr);
+// {s, 1/s} from the float bits at out4[2] (e3_scale.hip)
+int scale_finalize(float* out4, int target_log2, hipStream_t s);
 
 // name of the kernel family the last fused forward of this thread launched (diagnostics / bench labels)
 void fast_note_kernel(const char* name);

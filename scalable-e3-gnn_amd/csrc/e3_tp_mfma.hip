@@ -198,7 +198,8 @@ const char* fast_last_kernel() { return g_last_kernel; }
 
 int fast_forward(const TpFast* F, const e3_tp_segment* segs, int nseg, int D1, const void* in2, int64_t ld2,
                  const void* packed, void* out, int64_t ldo, int64_t B, int gate, int dtype, const int32_t* ocol_tab,
-                 const float* in_scale, hipStream_t s, const int32_t* scatter) {
+                 const float* in_scale, hipStream_t s, const int32_t* scatter, const void* residual, int64_t ldr,
+                 uint32_t* amax) {
   if (!F->usable) return E3_ERR_UNSUPPORTED;
   const bool io16 = dtype == E3_BF16;
   const FDev& d = F->dev;
@@ -219,6 +220,10 @@ int fast_forward(const TpFast* F, const e3_tp_segment* segs, int nseg, int D1, c
   for (int i = nseg; i < 5; ++i) sa.col0[i] = col;
   sa.nseg = nseg;
   sa.scatter = scatter;
+  sa.residual = residual;
+  sa.ldr = ldr;
+  sa.amax = amax;
+  if (residual && ldr >= (int64_t)1 << 29) return E3_ERR_UNSUPPORTED;
   if (col != D1) return E3_ERR_INVALID_ARG;
   for (auto& ch : F->h_chunks) {  // a chunk must not straddle two segments
     int cw = ch.count * (2 * ch.l1 + 1), sidx = 0;

@@ -89,6 +89,10 @@ struct SegArgs {
   int col0[5];  // first in1 column of each segment; col0[nseg] = D1
   int nseg;
   const int32_t* scatter;  // fused segment-sum (e3_tp_forward_fused_scatter): node id of every row, ascending; else null
+  // epilogue extras (e3_tp_forward_fused_epilogue; plain stores only): out = product + residual, and the running max |out|
+  const void* residual;    // [B, out width], storage dtype, same column layout as out; null = none
+  int64_t ldr;
+  uint32_t* amax;          // float bits, atomicMax of every finite |out| this launch wrote; null = none
 };
 
 __device__ __forceinline__ float sigmoid_(float v) { return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }

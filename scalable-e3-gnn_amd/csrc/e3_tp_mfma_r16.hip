@@ -249,6 +249,7 @@ __global__ __launch_bounds__(256, r16_waves_per_simd(NT0, NT1, NT2)) void tp_fwd
   const int inv_dy = (65536 + Dy - 1) / Dy;
   using Slots = PathSlots<LSH, NT0, NT1, NT2>;
   using Seq = IntSeq<L1S...>;
+  float amax = 0.f;  // running max |out| of this lane's stores (epilogue extras)
 
   for (int64_t tile = tile0; tile < ntiles; tile += tstride) {
     const int64_t row0 = tile * 16;
@@ -395,7 +396,8 @@ __global__ __launch_bounds__(256, r16_waves_per_simd(NT0, NT1, NT2)) void tp_fwd
     float* ot = cbuf;
     // this lane's 8 channels of a 32-channel tile: q = 4 * (16-tile) + r  ->  channel 16 * (q >> 2) + 4 * g + (q & 3)
     auto chan_of = [&](int q) { return 16 * (q >> 2) + 4 * g + (q & 3); };
-    const bool out_vec = !(ldo & 3) && ((reinterpret_cast<uintptr_t>(outv) & 15) == 0);
+    const bool out_vec = !(ldo & 3) && ((reinterpret_cast<uintptr_t>(outv) & 15) == 0) &&
+                         (!segs.residual || (!(segs.ldr & 3) && (reinterpret_cast<uintptr_t>(segs.residual) & 15) == 0));
     auto emit = [&](auto dtag, auto val, auto col, auto ncol, const int width, const bool affine) {
       constexpr int D = decltype(dtag)::value;
       constexpr int TS = 32 * D + 4;
@@ -446,6 +448,20 @@ __global__ __launch_bounds__(256, r16_waves_per_simd(NT0, NT1, NT2)) void tp_fwd
           if ((int)row < nrows && (int)lc0 < width) {
             v.x *= n0; v.y *= n1; v.z *= n2; v.w *= n3;
             const uint32_t o = __umul24(row, ldo32) + (uint32_t)colb + lc0;
+            if constexpr (!SCAT) {
+              if (segs.residual) {
+                const int64_t ro = (row0 + row) * segs.ldr + colb + lc0;
+                if (IO16) {
+                  const uint2 rk = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(segs.residual) + ro);
+                  v.x += __builtin_bit_cast(float, rk.x << 16); v.y += __builtin_bit_cast(float, rk.x & 0xffff0000u);
+                  v.z += __builtin_bit_cast(float, rk.y << 16); v.w += __builtin_bit_cast(float, rk.y & 0xffff0000u);
+                } else {
+                  const float4 rv = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(segs.residual) + ro);
+                  v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+                }
+              }
+              amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+            }
             if (IO16) {
               uint2 pk;
               pk.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{v.x, v.y}, bf16x2_t));
@@ -465,7 +481,13 @@ __global__ __launch_bounds__(256, r16_waves_per_simd(NT0, NT1, NT2)) void tp_fwd
           const float* src = ot + lc;
 #pragma unroll 1
           for (int r = 0; r < nrows; ++r) {
-            const float v = src[r * TS] * nv;
+            float v = src[r * TS] * nv;
+            if (segs.residual) {
+              const int64_t ro = (row0 + r) * segs.ldr + col(lc);
+              v += IO16 ? __builtin_bit_cast(float, (uint32_t)reinterpret_cast<const uint16_t*>(segs.residual)[ro] << 16)
+                        : reinterpret_cast<const float*>(segs.residual)[ro];
+            }
+            amax = fmaxf(amax, fabsf(v));
             if (IO16)
               reinterpret_cast<uint16_t*>(outv)[c0 + (int64_t)r * ldo] = __builtin_bit_cast(uint16_t, (__bf16)v);
             else
@@ -543,6 +565,14 @@ __global__ __launch_bounds__(256, r16_waves_per_simd(NT0, NT1, NT2)) void tp_fwd
       for (int t = 0; t < NT1; ++t) tile(I3{}, 1, t, [&](int q, int c) { return a1[2 * t + (q >> 2)][c][q & 3]; });
 #pragma unroll
       for (int t = 0; t < NT2; ++t) tile(I5{}, 2, t, [&](int q, int c) { return a2[2 * t + (q >> 2)][c][q & 3]; });
+    }
+  }
+  if constexpr (!SCAT) {
+    if (segs.amax) {  // NaN / inf leave the maximum at the largest finite value seen (as e3_pow2_scale does)
+      amax = amax < INFINITY ? amax : 0.f;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+      if (lane == 0 && amax > 0.f) atomicMax(segs.amax, __builtin_bit_cast(uint32_t, amax));
     }
   }
 }
@@ -627,6 +657,7 @@ int fast_forward_r16(const TpFast* F, const void* sa_, const void* in2, int64_t 
   const R16KernelEntry* e = r16_find(F);
   if (!e) return 0;
   if (scat && (io16 || !gate || !e->fn_scat)) return 0;
+  if (scat && (static_cast<const SegArgs*>(sa_)->residual || static_cast<const SegArgs*>(sa_)->amax)) return 0;
   const void* fn = scat ? e->fn_scat : e->fn[io16 ? 1 : 0][gate ? 1 : 0];
   const size_t lds_bytes = r16_lds_bytes(F, kR16Waves);
   if ((size_t)r16_waves_per_simd(d.NT[0], d.NT[1], d.NT[2]) * lds_bytes > (size_t)kFastLds) return 0;

@@ -338,13 +338,15 @@ class L1TensorProduct(Module):
     def fused_supported(self, gate: bool) -> bool:
         return self._fused_plan().fused_supported(gate)
 
-    def forward_fused(self, segments, in2: Tensor, gate: bool = False, scatter=None, in_scale=None):
+    def forward_fused(self, segments, in2: Tensor, gate: bool = False, scatter=None, in_scale=None, residual=None,
+                      out_scale=None):
         """``scatter=(row_node, n_nodes)``: fused segment-sum (see ``TPPlan.forward_fused``); returns None when the
-        library has no such kernel for this product (callers then run the two kernels)."""
+        library has no such kernel for this product (callers then run the two kernels).  ``residual`` / ``out_scale``:
+        residual add and operand scale of the result in the kernel's epilogue (-> (out, scale) with ``out_scale``)."""
         ws = self._weights() + [None, None]
         ns = self._norms() + [None, None]
         return self._fused_plan().forward_fused(ws, ns, segments, in2, gate, tag=f"{self.iri1}->{self.iro}",
-                                                scatter=scatter, in_scale=in_scale)
+                                                scatter=scatter, in_scale=in_scale, residual=residual, out_scale=out_scale)
 
     # ------------------------------------------------------------------------------------------
     def forward(self, in1: Tensor, in2: Tensor) -> Tensor:

@@ -156,6 +156,15 @@ class SEGNNLayer(nn.Module):
             sc = None
             if f32 and h_scale is not None and halo is None:
                 sc = ops.join_pow2_scales(h_scale, ops.pow2_scale([a]))
+            if self.upd2.fused_supported(False) and h.stride(-1) == 1:
+                # the scale of u comes out of update #1's epilogue; update #2 adds the residual and emits the scale of the
+                # new h in its own: no pass over [N, width] outside the two products
+                u, u_scale = self.upd1.forward_fused([(h, None), (a, None)], A, gate=True, in_scale=sc,
+                                                     out_scale=10 if f32 else None) if f32 else \
+                    (self.upd1.forward_fused([(h, None), (a, None)], A, gate=True), None)
+                if f32:
+                    return self.upd2.forward_fused([(u, None)], A, gate=False, in_scale=u_scale, residual=h, out_scale=10)
+                return self.upd2.forward_fused([(u, None)], A, gate=False, residual=h), None
             u = self.upd1.forward_fused([(h, None), (a, None)], A, gate=True, in_scale=sc)
         else:
             u = self._gate(self.upd1(torch.cat([h, a], 1), A))

@@ -123,11 +123,14 @@ class TPPlan:
     def invalidate_packed(self):
         self._packed = {}
 
-    def forward_fused(self, ws, ns, segments, in2, gate: bool, tag="", scatter=None, in_scale=None):
+    def forward_fused(self, ws, ns, segments, in2, gate: bool, tag="", scatter=None, in_scale=None, residual=None,
+                      out_scale=None):
         """segments: [(tensor [R, ncols], row_index int32 [B] | None), ...]; -> [B, out_dim or gated width].
         scatter = (row_node int32 [B] ascending, n_nodes): rows are summed per node instead of stored (fused
         segment-sum, fp32 atomics) -> [n_nodes, width]; returns None when the library has no such kernel for this plan.
-        in_scale: power-of-two operand scale of the segments (``ops.pow2_scale``); computed here when None (fp32)."""
+        in_scale: power-of-two operand scale of the segments (``ops.pow2_scale``); computed here when None (fp32).
+        residual [B, width]: added to the result in the kernel's epilogue.  out_scale = target_log2 (int): also return the
+        operand scale of the result, ``ops.pow2_scale([out], target_log2)``, taken in the same epilogue -> (out, scale)."""
         lib = _lib.load()
         B = in2.shape[0]
         dev = in2.device
@@ -166,7 +169,9 @@ class TPPlan:
         else:
             out = torch.empty((B, width), dtype=io, device=dev)
         if B == 0:
-            return out
+            if residual is not None:
+                out = residual.clone()
+            return (out, torch.tensor([1.0, 1.0, 0.0, 0.0], device=dev)) if out_scale is not None else out
         if in2.stride(-1) != 1:
             in2 = in2.contiguous()
         esz = out.element_size()
@@ -179,7 +184,19 @@ class TPPlan:
             stream = torch.cuda.current_stream(dev).cuda_stream
             t0 = profiling.begin() if profiling.enabled() else None
             h = self.handle(dev)
-            if scatter is not None:
+            if residual is not None or out_scale is not None:
+                if scatter is not None:
+                    raise RuntimeError("forward_fused: residual / out_scale do not combine with scatter")
+                if residual is not None and (residual.shape != out.shape or residual.dtype != io or residual.stride(-1) != 1):
+                    raise RuntimeError(f"forward_fused: residual must be {tuple(out.shape)} {io}, contiguous rows")
+                sc4 = torch.empty(4, dtype=torch.float32, device=dev) if out_scale is not None else None
+                _lib.check(lib.e3_tp_forward_fused_epilogue(
+                    h, ctypes.byref(segs), len(segments), in2.data_ptr(), in2.stride(0), packed.data_ptr(), out.data_ptr(),
+                    out.stride(0), B, _lib.dtype_code(io), 1 if gate else 0, sc,
+                    residual.data_ptr() if residual is not None else None, residual.stride(0) if residual is not None else 0,
+                    sc4.data_ptr() if sc4 is not None else None, int(out_scale) if out_scale is not None else 0, stream),
+                    "e3_tp_forward_fused_epilogue")
+            elif scatter is not None:
                 st = lib.e3_tp_forward_fused_scatter(h, ctypes.byref(segs), len(segments), in2.data_ptr(),
                                                      in2.stride(0), packed.data_ptr(), scatter[0].data_ptr(),
                                                      out.data_ptr(), out.stride(0), B, _lib.dtype_code(io), 1, sc, stream)
@@ -200,6 +217,8 @@ class TPPlan:
                 mode = "<bf16 storage, bf16 MFMA>" if io == torch.bfloat16 else "<fp16x3 split MFMA>"
                 profiling.end(f"tp_fused{'+segsum' if scatter is not None else ''} {tag} B={B}", B, nb, t0, flops=self.flops_per_row * B,
                               kernel=(lib.e3_tp_last_fused_kernel() or b"e3::tp_fwd_mfma_r16_kernel").decode() + mode)
+        if out_scale is not None:
+            return out, sc4
         return out
 
 
@@ -364,12 +383,13 @@ class SHTensorProduct(nn.Module):
     def fused_supported(self, gate: bool) -> bool:
         return self._plan.fused_supported(gate)
 
-    def forward_fused(self, segments, in2, gate: bool = False, scatter=None, in_scale=None):
+    def forward_fused(self, segments, in2, gate: bool = False, scatter=None, in_scale=None, residual=None, out_scale=None):
         """TP over ``in1 = [seg0[idx0] | seg1[idx1] | ...]`` (gather + concat fused), optional fused gate, optional
-        fused segment-sum (``scatter=(row_node, n_nodes)``, see ``TPPlan.forward_fused``; None = unsupported)."""
+        fused segment-sum (``scatter=(row_node, n_nodes)``, see ``TPPlan.forward_fused``; None = unsupported), optional
+        residual add and operand scale of the result (``residual``, ``out_scale``)."""
         ws, ns = self._tensors()
         return self._plan.forward_fused(ws, ns, segments, in2, gate, tag=f"{self.iri1}->{self.iro}", scatter=scatter,
-                                        in_scale=in_scale)
+                                        in_scale=in_scale, residual=residual, out_scale=out_scale)
 
     def forward(self, in1: torch.Tensor, in2: torch.Tensor) -> torch.Tensor:
         torch._assert(in1.shape[-1] == self.in1_dim,

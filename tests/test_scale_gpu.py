@@ -53,3 +53,38 @@ def test_add_pow2_scale_matches_separate_ops():
     out, sc = ops.add_pow2_scale(h, u)
     assert torch.equal(out, h + u)
     assert torch.equal(sc[:2], ops.pow2_scale([h + u])[:2])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("irreps,out,gate,lmax,B", [
+    ("32x0e+32x1o+32x2e", "32x0e+32x1o+32x2e", False, 2, 4099),             # update product #2 (l_max = 2)
+    ("32x0e+32x1o", "32x0e+32x1o", False, 1, 1000),                         # update product #2 (l_max = 1)
+    ("32x0e+32x1o+32x2e", "32x0e+64x0e+32x1o+32x2e", True, 2, 2050),        # gated
+])
+def test_fused_epilogue_residual_and_scale(irreps, out, gate, lmax, B, dtype):
+    """e3_tp_forward_fused_epilogue: `out = product + residual` and the operand scale of `out`, both in the product's
+    epilogue, against the product followed by a torch add and ops.pow2_scale."""
+    from scalable_e3_gnn_amd.tensor_product import SHTensorProduct
+    torch.manual_seed(4)
+    mod = SHTensorProduct(irreps, out, lmax).to(DEV).to(dtype)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = (torch.randn(B, mod.in1_dim, device=DEV, generator=g) * 3).to(dtype)
+    y = torch.randn(B, mod.in2_dim, device=DEV, generator=g)
+    with torch.no_grad():
+        plain = mod.forward_fused([(x, None)], y, gate=gate)
+        res = (torch.randn(plain.shape, device=DEV, generator=g) * 50).to(dtype)
+        res[B // 2, 7] = 7e3                                                          # the maximum sits in one known element
+        if dtype == torch.float32:
+            got, sc = mod.forward_fused([(x, None)], y, gate=gate, residual=res, out_scale=10)
+            want = plain + res
+            assert torch.equal(got, want)                                             # the same fp32 add, in the epilogue
+            ref = ops.pow2_scale([want], target_log2=10)
+            assert float(sc[0]) == float(ref[0]) and float(sc[1]) == float(ref[1])
+            assert float(sc[2].view(torch.int32).view(torch.float32)) == float(want.abs().max())
+            # scale only
+            got2, sc2 = mod.forward_fused([(x, None)], y, gate=gate, out_scale=9)
+            assert torch.equal(got2, plain) and float(sc2[0]) == float(ops.pow2_scale([plain], target_log2=9)[0])
+        else:
+            got = mod.forward_fused([(x, None)], y, gate=gate, residual=res)
+            want = plain.float() + res.float()                                        # one rounding of the fp32 sum in the kernel
+            assert (got.float() - want).abs().max() <= 2.0 ** -7 * want.abs().max()
