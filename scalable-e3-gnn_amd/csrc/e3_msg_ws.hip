@@ -235,6 +235,19 @@ __device__ __forceinline__ void ws_load_w(const float* packed, const int prod /*
 #ifndef WS_PF
 #define WS_PF 2
 #endif
+// Whole-vector forms (f32x4 fma / products -> v_pk_fma_f32 / v_pk_mul_f32 with the per-edge factor broadcast through op_sel) of
+// the folds and the gate epilogues, fp32 storage only (bf16 storage measured 4 % slower with them).  bit 0: folds with table
+// couplings, 1: folds with one-harmonic couplings, 2: epilogue of product #2, 3: epilogue of product #1.  Measured 19.76 ->
+// 19.50 ms per launch pair: the product waves are bound by LDS reads and dependent-MFMA latency more than by vector issue.
+#ifndef WS_PKT
+#define WS_PKT 15
+#endif
+// per table coupling: bit 0 (1,1,2), 1 (1,2,1), 2 (2,1,1), 3 (2,2,2).  Path (2, 1, 1) stays in scalar form: its vector form gives
+// wrong sums with this compiler (hipcc 7.2; the other three and every other use check out against the oracle) --
+// tools/build_variant.sh x "-DWS_PKZ=15" e3_msg_ws + tools/exp_check.py x tests/test_msg_fused_gpu.py reproduces it.
+#ifndef WS_PKZ
+#define WS_PKZ 11
+#endif
 #ifndef WS_PRIO
 #define WS_PRIO 0   // s_setprio of a product wave while it multiplies (0: none; 2 measured 20.4 vs 19.6 ms: the partner waves are near-critical too)
 #endif
@@ -320,8 +333,7 @@ struct TpRun {
     const uint4 xh = bh[slot], xl = bl[slot];
     if constexpr (a >= 0) {
       if constexpr (L1 == 0 && FIRST && LV > 0) {  // distance channel of product #1: couples through (0, l, l)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) uV[0][LV][0][r] = __builtin_fmaf(wdV[r], dsc, uV[0][LV][0][r]);
+        uV[0][LV][0] = __builtin_elementwise_fma(wdV, f32x4{dsc, dsc, dsc, dsc}, uV[0][LV][0]);
       }
       sfor3([&](auto l2tag) {
         constexpr int L2 = decltype(l2tag)::value;
@@ -353,9 +365,15 @@ struct TpRun {
 #pragma unroll
             for (int aa = 0; aa < D1; ++aa)
               if (z_nonzero<L1, L2, LV>(aa, c)) {
+                // whole-vector form: two v_pk_fma_f32 with the coupling broadcast through op_sel instead of four v_fmac
                 const float z = zq[L1][L2][(aa * D3 + c) >> 2][(aa * D3 + c) & 3];
+                constexpr int zi = (L1 == 1 && L2 == 1) ? 0 : (L1 == 1 && L2 == 2) ? 1 : (L1 == 2 && L2 == 1) ? 2 : 3;
+                if constexpr (!IO16 && (WS_PKT & 1) && ((WS_PKZ >> zi) & 1)) {
+                  accV[c] = __builtin_elementwise_fma(uV[L1][L2][aa], f32x4{z, z, z, z}, accV[c]);
+                } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) accV[c][r] = __builtin_fmaf(uV[L1][L2][aa][r], z, accV[c][r]);
+                  for (int r = 0; r < 4; ++r) accV[c][r] = __builtin_fmaf(uV[L1][L2][aa][r], z, accV[c][r]);
+                }
               }
         } else {  // (0, l, l) and (l, 0, l): one harmonic times a constant
           float y9[9];
@@ -368,8 +386,12 @@ struct TpRun {
 #pragma unroll
             for (int aa = 0; aa < D1; ++aa)
               if (z_nonzero<L1, L2, LV>(aa, c)) {
+                if constexpr (!IO16 && (WS_PKT & 2)) {
+                  accV[c] = __builtin_elementwise_fma(uV[L1][L2][aa], f32x4{zz[aa][c], zz[aa][c], zz[aa][c], zz[aa][c]}, accV[c]);
+                } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) accV[c][r] = __builtin_fmaf(uV[L1][L2][aa][r], zz[aa][c], accV[c][r]);
+                  for (int r = 0; r < 4; ++r) accV[c][r] = __builtin_fmaf(uV[L1][L2][aa][r], zz[aa][c], accV[c][r]);
+                }
               }
         }
       }
@@ -802,15 +824,22 @@ __device__ __forceinline__ void ws_run(const WsArgs& A, unsigned char* smem) {
         if constexpr (O::LV > 0) {  // a lane's 4 channels x (2l+1) components are contiguous in the output row
           constexpr int Dc = 2 * O::LV + 1;
           const f32x4 gn = nt[4 * O::tG];
-          float gt[4];
+          f32x4 gt;
 #pragma unroll
           for (int r = 0; r < 4; ++r) gt[r] = sigmoid_(accG[r] * gn[r] * isrow) * isrow;
           float o[4 * Dc];
 #pragma unroll
           for (int c = 0; c < Dc; ++c) {
             const f32x4 nv = nt[4 * (G::slot0(O::LV) + Dc * O::t + c)];
+            f32x4 oc;
+            if constexpr (!IO16 && (WS_PKT & 4)) {
+              oc = accV[c] * nv * gt;  // whole-vector products: v_pk_mul_f32
+            } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r * Dc + c] = accV[c][r] * nv[r] * gt[r];
+              for (int r = 0; r < 4; ++r) oc[r] = accV[c][r] * nv[r] * gt[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r * Dc + c] = oc[r];
           }
           f32x4* dq = reinterpret_cast<f32x4*>(orow + G::col0(O::LV) + (16 * O::t + 4 * g) * Dc);
 #pragma unroll
@@ -858,7 +887,7 @@ __device__ __forceinline__ void ws_run(const WsArgs& A, unsigned char* smem) {
         if constexpr (O::LV > 0) {
           constexpr int Dc = 2 * O::LV + 1;
           const f32x4 gn = nt[4 * O::tG];
-          float gt[4];
+          f32x4 gt;
 #pragma unroll
           for (int r = 0; r < 4; ++r) gt[r] = sigmoid_(accG[r] * gn[r]);
           float y9[9];
@@ -866,18 +895,26 @@ __device__ __forceinline__ void ws_run(const WsArgs& A, unsigned char* smem) {
           for (int i = 0; i < 9; ++i) y9[i] = y[i];
           float zz[Dc][1];
           make_z<O::LV, O::LV, 0>(y9, zz);
-          float fs[4] = {0.f, 0.f, 0.f, 0.f};
+          f32x4 fsv = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int c = 0; c < Dc; ++c) {
             const f32x4 nv = nt[4 * (G::slot0(O::LV) + Dc * O::t + c)];
-            float f[4];
+            f32x4 fv;
+            if constexpr (!IO16 && (WS_PKT & 8)) {
+              fv = accV[c] * nv * gt;  // whole-vector products / fma: v_pk_mul_f32, v_pk_fma_f32
+              const f32x4 zc = {zz[c][0], zz[c][0], zz[c][0], zz[c][0]};
+              fsv = c == 0 ? zc * fv : __builtin_elementwise_fma(zc, fv, fsv);
+            } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              f[r] = accV[c][r] * nv[r] * gt[r];
-              fs[r] = c == 0 ? zz[0][0] * f[r] : __builtin_fmaf(zz[c][0], f[r], fs[r]);
+              for (int r = 0; r < 4; ++r) {
+                fv[r] = accV[c][r] * nv[r] * gt[r];
+                fsv[r] = c == 0 ? zz[0][0] * fv[r] : __builtin_fmaf(zz[c][0], fv[r], fsv[r]);
+              }
             }
+            const float f[4] = {fv[0], fv[1], fv[2], fv[3]};
             put4(L::frag(O::LV, c), f);
           }
+          const float fs[4] = {fsv[0], fsv[1], fsv[2], fsv[3]};
           put4(L::frag_ff(O::LV), fs);  // feature-first operand of product #2: f[k] = sum_c z[c] m[k][c]
         }
         if constexpr (ROLE == 3 && !IO16) {
