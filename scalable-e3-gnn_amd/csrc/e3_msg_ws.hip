@@ -646,14 +646,22 @@ __device__ __forceinline__ void ws_run(const WsArgs& A, unsigned char* smem) {
   uint32_t tpmk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   uint32_t st_acc[4] = {0, 0, 0, 0}, st_t = (uint32_t)__builtin_readcyclecounter();
 #define WS_STAMP(i) { const uint32_t t_ = (uint32_t)__builtin_readcyclecounter(); st_acc[i] += t_ - st_t; st_t = t_; }
+  // marks 5-7 of the tensor-product table: [5] phase start -> product start, [6] product end (or phase start) -> end of
+  // phase X, [7] the same for phase Y
+  uint32_t pm_t = 0;
+#define WS_PM0 { pm_t = (uint32_t)__builtin_readcyclecounter(); }
+#define WS_PM(i) { const uint32_t t_ = (uint32_t)__builtin_readcyclecounter(); tpmk[i] += t_ - pm_t; pm_t = t_; }
 #else
   uint32_t* const tpmk = nullptr;
 #define WS_STAMP(i)
+#define WS_PM0
+#define WS_PM(i)
 #endif
   TileInfo t0 = tinfo(0), t1 = tinfo(-1);
   for (int s = 0;; ++s) {
     if (s >= 1 && t1.n == 0) break;
     WS_STAMP(3)
+    WS_PM0
     // =========================================== phase X ===========================================
     if constexpr (W == 3) {
       cut(s + 1);
@@ -808,7 +816,9 @@ __device__ __forceinline__ void ws_run(const WsArgs& A, unsigned char* smem) {
         f32x4 accV[5], accG, accS;
         // (the product wave is the longest of its SIMD pair in either phase: it gets the vector issue slots first)
         __builtin_amdgcn_s_setprio(WS_PRIO);
+        WS_PM(5)
         ws_tp<LMAX, TT, ROLE, false, IO16>(w, smem + L::o_b2 + lane * 16, ztr, nullptr, nullptr, nullptr, accV, accG, accS, y, tpmk);
+        WS_PM0
         const f32x4* nt = reinterpret_cast<const f32x4*>(n2tab) + g;
         float* orow = reinterpret_cast<float*>(smem + L::o_o) + j * L::RS;
         if constexpr (O::tS >= 0) {
@@ -848,9 +858,11 @@ __device__ __forceinline__ void ws_run(const WsArgs& A, unsigned char* smem) {
       }
     }
     if constexpr (TEAM1) __builtin_amdgcn_s_setprio(0);
+    WS_PM(6)
     WS_STAMP(0)
     ws_barrier();
     WS_STAMP(1)
+    WS_PM0
     // =========================================== phase Y ===========================================
     if constexpr (!TEAM1) {
       // ---- team 0: product #1 + gate #1 of tile s; the gated messages leave as the B fragments of product #2 ----
@@ -863,8 +875,10 @@ __device__ __forceinline__ void ws_run(const WsArgs& A, unsigned char* smem) {
         const float* urow = reinterpret_cast<const float*>(smem + L::o_u + slot * L::U_ROW) + 4 * g;
         f32x4 accV[5], accG, accS;
         __builtin_amdgcn_s_setprio(WS_PRIO);
+        WS_PM(5)
         ws_tp<LMAX, TT, ROLE, true, IO16>(w, smem + L::o_b1 + lane * 16, ztr, urow, wdtab + 4 * g,
                                           reinterpret_cast<const f32x4*>(smem + L::o_init) + lane, accV, accG, accS, y, tpmk);
+        WS_PM0
         const float dsc = y[9];
         // row scale of the fp16 split: bound of the row's messages -> [2^12, 2^13)  (identical in the four waves: it depends
         // on the row's inputs only)
@@ -968,6 +982,7 @@ __device__ __forceinline__ void ws_run(const WsArgs& A, unsigned char* smem) {
     }
     if constexpr (!TEAM1) __builtin_amdgcn_s_setprio(0);
     const TileInfo tn = tinfo(s + 1);  // published in phase X; read here so that its latency hides behind the barrier wait
+    WS_PM(7)
     WS_STAMP(2)
     ws_barrier();
     t1 = t0; t0 = tn;

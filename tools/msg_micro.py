@@ -69,8 +69,9 @@ for tpb in [int(v) for v in os.environ.get("TPB", "0").split(",")]:
             print(f"   wave {w}: {v[0]:8.0f} {v[1]:8.0f} {v[2]:8.0f} {v[3]:8.0f}   sum {sum(v):8.0f}")
         print("   tensor product marks, cycles per tile: [first requests | degree 2 | degree 1 (+fold 2) | degree 0 (+fold 1) | fold 0]  (rest of the phase = gate + stores)")
         for w in range(8):
-            v = [buf[32 + 8 * w + i] / nwg / steps for i in range(5)]
-            print(f"   wave {w}: " + " ".join(f"{x:7.0f}" for x in v) + f"   sum {sum(v):7.0f}")
+            v = [buf[32 + 8 * w + i] / nwg / steps for i in range(8)]
+            print(f"   wave {w}: " + " ".join(f"{x:7.0f}" for x in v[:5]) + f"   sum {sum(v[:5]):7.0f}   | before product {v[5]:6.0f}"
+                  f" | X after product / all of X {v[6]:6.0f} | Y after product / all of Y {v[7]:6.0f}")
     fl = layer._msg.flops_per_edge() * E
     print(f"[{os.environ.get('E3_EXP_LIB','default')}] N={N} E={E} lmax={lmax} H={H} tpb={tpb} zero_idx={bool(edges)}: {ms:.2f} ms/launch pair  {E/ms/1e3:.0f} Medges/s  "
           f"{fl/ms/1e9:.1f} TFLOP/s algorithmic ({3*fl/ms/1e9/2500*100:.1f} % of bf16/f16 MFMA peak executed x3)")
