@@ -1,5 +1,5 @@
 import sys, numpy as np, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import models  # noqa
 from scalable_e3_gnn_amd import ops
 from scalable_e3_gnn_amd.radius_graph import radius_graph

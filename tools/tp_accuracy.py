@@ -1,5 +1,5 @@
 import sys, numpy as np, torch
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import models
 from oracle import tp_oracle as T
 from scalable_e3_gnn_amd.tensor_product import SHTensorProduct
