@@ -300,6 +300,22 @@ class L1TensorProduct(Module):
         ld2 = 0 if (in2.shape[0] == 1 and B != 1) else in2.stride(0)
         code = _lib.dtype_code(dtype)
         from . import tensor_product as _tp
+        if (B >= _tp._BWD_GEMM_MIN_ROWS and dtype == torch.float32 and need_in1 and not need_in2 and ld2 != 0 and
+                getattr(self, "is_comp_norm", False)):
+            # grad_in1 alone (the training case: harmonics of fixed positions) = THIS operator on the transposed plan:
+            # C(l1,l2,l3)[a,b,c] = +-C(l3,l2,l1)[c,b,a], so grad_in1 = dual(grad_out * norm, in2) with the weight blocks
+            # transposed (and the cross-product block negated) -- one launch of the MFMA forward kernel, nothing of size
+            # [B, D3, K] in HBM.  grad_W still comes from the operand pass + one batched GEMM per class.
+            g1 = self._dual_forward(ws, ns, in1, in2, grad_out)
+            gws = [None] * 6
+            if need_w:
+                tpp = self._fused_plan()
+                ws6, ns6 = list(ws) + [None, None], list(ns) + [None, None]
+                with torch.cuda.device(device):
+                    packed = tpp.packed(ws6, ns6, dtype, device)
+                _, _, gws = _tp.tp_backward(tpp, packed, in1, in2, grad_out, ws6, False, False,
+                                            [w is not None for w in ws6])
+            return (g1, None, {c: (gws[i].to(ws[i].dtype) if gws[i] is not None else None) for i, c in enumerate(_CLS)})
         if B >= _tp._BWD_GEMM_MIN_ROWS and dtype in (torch.float32, torch.float64):
             # large B: operands -> library GEMMs -> contract on the general plan (this operator is its lmax_sh = 1 case:
             # same class order, weight-row order and norms, see forward_fused)
@@ -325,6 +341,68 @@ class L1TensorProduct(Module):
                 g_in2.data_ptr() if g_in2 is not None else None,
                 _lib.ptr4([g_w[c] for c in _CLS]), work.data_ptr(), B, code, stream), "e3_l1tp_backward")
         return g_in1, g_in2, g_w
+
+    def _dual_forward(self, ws, ns, in1, in2, grad_out):
+        """grad_in1 of the forward as a forward of the dual operator (irreps swapped, lmax 1).  Weight rows of the forward
+        (`L1TP.py:81-88`): l0e [0e | 1o], l0o [0o | 1e], l1e [0o | 1e | 1o x], l1o [0e | 1o | 1e x]; the dual's rows are the
+        same lists with the multiplicities of the OUT irreps, each block the transpose of the forward block that connects the
+        two classes, the cross-product blocks (`cg111`, antisymmetric) negated.  Norms leave with grad_out."""
+        dual = getattr(self, "_dual", None)
+        dev = in1.device
+        if dual is None:
+            with torch.random.fork_rng(devices=[]):   # the constructor draws weights: leave the caller's RNG stream alone
+                dual = L1TensorProduct(self.iro, self.iri1)
+            for c in _CLS:
+                getattr(dual, "norm_" + c).fill_(1.0)
+            dual.requires_grad_(False)
+            object.__setattr__(self, "_dual", dual)   # not a submodule: no parameters of its own, rebuilt from self's
+        if dual._weights()[0] is None and dual._weights()[1] is None and dual._weights()[2] is None and dual._weights()[3] is None:
+            return torch.zeros_like(in1, memory_format=torch.contiguous_format)
+        if next((w for w in dual._weights() if w is not None)).device != dev or \
+                next((w for w in dual._weights() if w is not None)).dtype != in1.dtype:
+            dual.to(device=dev, dtype=in1.dtype)
+        n0e, n0o, n1e, n1o = self.num_i1_l0e, self.num_i1_l0o, self.num_i1_l1e, self.num_i1_l1o
+        W = dict(zip(_CLS, ws))
+
+        def blk(c, r0, n):   # rows r0 .. r0 + n of the forward matrix of class c, transposed; zeros when the class is absent
+            w = W[c]
+            return None if (w is None or n == 0) else w.detach()[r0:r0 + n].t()
+
+        rows = {   # dual class -> [(block or None, rows of the block = multiplicity of the dual's in class), ...]
+            "l0e": [(blk("l0e", 0, n0e), dual.num_i1_l0e, 1.0), (blk("l1o", 0, n0e), dual.num_i1_l1o, 1.0)],
+            "l0o": [(blk("l0o", 0, n0o), dual.num_i1_l0o, 1.0), (blk("l1e", 0, n0o), dual.num_i1_l1e, 1.0)],
+            "l1e": [(blk("l0o", n0o, n1e), dual.num_i1_l0o, 1.0), (blk("l1e", n0o, n1e), dual.num_i1_l1e, 1.0),
+                    (blk("l1o", n0e + n1o, n1e), dual.num_i1_l1o, -1.0)],
+            "l1o": [(blk("l0e", n0e, n1o), dual.num_i1_l0e, 1.0), (blk("l1o", n0e, n1o), dual.num_i1_l1o, 1.0),
+                    (blk("l1e", n0o + n1e, n1o), dual.num_i1_l1e, -1.0)],
+        }
+        with torch.no_grad():
+            for c in _CLS:
+                wd = getattr(dual, "weights_" + c, None)
+                if wd is None:
+                    continue
+                r = 0
+                for b, nrows, sign in rows[c]:
+                    if nrows == 0:
+                        continue
+                    if b is None:
+                        wd[r:r + nrows].zero_()
+                    else:
+                        wd[r:r + nrows].copy_(b if sign > 0 else -b)
+                    r += nrows
+                assert r == wd.shape[0], (c, r, tuple(wd.shape))
+            # grad_out * norm, per output column (class norms scattered to the out layout)
+            key = tuple((t.data_ptr(), t._version) if t is not None else None for t in ns) + (dev, in1.dtype)
+            if getattr(self, "_normcol_key", None) != key:
+                full = torch.ones(len(self.iro_l0e), dtype=in1.dtype, device=dev)
+                for c, n in zip(_CLS, ns):
+                    m = getattr(self, "iro_" + c)
+                    if n is not None and n.numel() and bool(m.any()):
+                        full[m.to(dev)] = n.to(in1.dtype)
+                object.__setattr__(self, "_normcol", full)
+                object.__setattr__(self, "_normcol_key", key)
+            gt = grad_out * self._normcol
+            return dual._hip_forward(gt, in2)
 
     # ------------------------------------------------------------------------------------------
     # Fused message-function form (builder-defined extension; same arithmetic, same weights): the row gather

@@ -60,25 +60,27 @@ def test_forward_matches_reference_golden(name, kernel):
     close(out, z["out"], TOL[c["dtype"]], name)
 
 
-@pytest.mark.parametrize("path", ["kernels", "gemm"])
+@pytest.mark.parametrize("path", ["kernels", "gemm", "dual"])
 @pytest.mark.parametrize("name", sorted(META["cases"]))
 def test_backward_matches_reference_golden(name, path, monkeypatch):
     """path: the operator's own 16-row kernels (small B) / operands -> library GEMMs -> contract on the general plan
-    (`tensor_product.tp_backward`, what large B runs)."""
+    (`tensor_product.tp_backward`, what large B runs) / `dual`: in2 needs no gradient (the training case), grad_in1 = the
+    forward kernel on the transposed operator (`L1TensorProduct._dual_forward`, fp32), grad_W = operands + GEMM."""
     from scalable_e3_gnn_amd import tensor_product as TPM
-    monkeypatch.setattr(TPM, "_BWD_GEMM_MIN_ROWS", 0 if path == "gemm" else 1 << 30)
+    monkeypatch.setattr(TPM, "_BWD_GEMM_MIN_ROWS", 0 if path != "kernels" else 1 << 30)
     c = META["cases"][name]
     z = load_case(name)
     mod = module_from_case(c, z)
     dt = TDT[c["dtype"]]
     x = torch.tensor(z["in1"]).to(dt).to(DEV).requires_grad_(True)
-    y = torch.tensor(z["in2"]).to(dt).to(DEV).requires_grad_(True)
+    y = torch.tensor(z["in2"]).to(dt).to(DEV).requires_grad_(path != "dual")
     go = torch.tensor(z["grad_out"]).to(dt).to(DEV)
     out = mod(x, y)
     (out * go).sum().backward()
     tol = TOL[c["dtype"]] * (4 if c["dtype"] != "float64" else 1)
     close(x.grad, z["grad_in1"], tol, name + " grad_in1")
-    close(y.grad, z["grad_in2"], tol, name + " grad_in2")
+    if path != "dual":
+        close(y.grad, z["grad_in2"], tol, name + " grad_in2")
     for k, p in mod.named_parameters():
         close(p.grad, z["grad_" + k], tol, f"{name} grad_{k}")
 
