@@ -248,6 +248,12 @@ __device__ __forceinline__ void ws_load_w(const float* packed, const int prod /*
 // right in front of its use (it minimises registers): ~25 exposed LDS round trips per product; the requests are therefore
 // pinned with sched_barrier.  All indices are compile-time constants (operand ring = registers).
 // ------------------------------------------------------------------------------------------------------------------
+#ifndef WS_XROT
+#define WS_XROT 2   // measured 19.43 -> 19.00 ms per launch pair (1: 19.24, 3: 19.38)
+#endif
+#ifndef WS_YROT
+#define WS_YROT 0
+#endif
 #ifndef WS_PF
 #define WS_PF 2
 #endif
@@ -482,6 +488,12 @@ __device__ __forceinline__ void ws_run(const WsArgs& A, unsigned char* smem) {
   constexpr int H = G::H, D = G::D, ES = L::ES;
   constexpr bool TEAM1 = W >= 4;
   constexpr int ROLE = W & 3;
+  // service job of a team-0 wave in phase X: 0 / 1 conversion of rows 0-7 / 8-15 (+ initial values), 2 initial values + edge
+  // table, 3 the tile cutter.  Rotated against the product roles (WS_XROT) so that the two conversion waves -- the longest,
+  // vector-heavy jobs -- share their SIMDs with the lighter roles of product #2 (l3 = 1 tiles: waves 6, 7), not with the
+  // l3 = 2 roles (waves 4, 5), which are the longest of phase X
+  constexpr int SX = TEAM1 ? -1 : ((W + WS_XROT) & 3);
+  constexpr int SY = TEAM1 ? ((W + WS_YROT) & 3) : -1;  // phase Y jobs of team 1: 0 / 1 run sums, 2 / 3 row copies
   using O = Own<LMAX, TT, ROLE>;
   using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
   const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
@@ -626,7 +638,7 @@ __device__ __forceinline__ void ws_run(const WsArgs& A, unsigned char* smem) {
     issue_ids(tile + 1);
   };
 
-  if constexpr (W == 3) {
+  if constexpr (SX == 3) {
     chunk_start(0);
     issue_ids(0);
     ws_wait_vm0();
@@ -641,8 +653,8 @@ __device__ __forceinline__ void ws_run(const WsArgs& A, unsigned char* smem) {
 
   // run-sum state of waves 4 / 5: column chunks {0, 1, 2} / {3, 4}
   constexpr int NQ = (D + 63) / 64;
-  constexpr bool RSW = TEAM1 && ROLE < 2;
-  constexpr int Q0 = !RSW ? 0 : (ROLE == 0 ? 0 : (NQ + 1) / 2), Q1 = !RSW ? 0 : (ROLE == 0 ? (NQ + 1) / 2 : NQ);
+  constexpr bool RSW = SY == 0 || SY == 1;
+  constexpr int Q0 = !RSW ? 0 : (SY == 0 ? 0 : (NQ + 1) / 2), Q1 = !RSW ? 0 : (SY == 0 ? (NQ + 1) / 2 : NQ);
   constexpr int NQW = Q1 - Q0 > 0 ? Q1 - Q0 : 1;
   int cur = -1;
   float carry[NQW];
@@ -679,14 +691,14 @@ __device__ __forceinline__ void ws_run(const WsArgs& A, unsigned char* smem) {
     WS_STAMP(3)
     WS_PM0
     // =========================================== phase X ===========================================
-    if constexpr (W == 3) {
+    if constexpr (SX == 3) {
       cut(s + 1);
     } else if constexpr (!TEAM1) {
       // ---- gathered rows of tile s -> B fragments of product #1.  Wave p (0, 1) converts rows 8 p .. 8 p + 7 of every
       //      degree: lane = (row j8, channel group g, half pc) handles ONE piece (4 channels x all components) per degree,
       //      i.e. half of a fragment lane's 8 k slots -> 8-byte stores of the hi and the lo halves ----
-      if (W <= 1 && t0.n > 0) {
-        const int j8 = lane & 7, gg = (lane >> 3) & 3, pc = lane >> 5, row = 8 * W + j8;
+      if (SX <= 1 && t0.n > 0) {
+        const int j8 = lane & 7, gg = (lane >> 3) & 3, pc = lane >> 5, row = 8 * SX + j8;
         const unsigned char* gimg = smem + L::o_g;
         unsigned char* b1 = smem + L::o_b1 + (16 * gg + row) * 16 + 8 * pc;
         // all reads first: positions, then the three pieces
@@ -747,7 +759,7 @@ __device__ __forceinline__ void ws_run(const WsArgs& A, unsigned char* smem) {
       // ---- wave 2: the edge table of tile s (harmonics, distance, dense couplings); waves 0-2: the initial values of the
       //      scalar-type tiles of product #1 (two tiles each): pre-mix of (0, 0, 0) + d-term + the pre-mix of the feature-first paths folded with their
       //      couplings -- all of it used to be recomputed / folded by the four product waves ----
-      if (W <= 2 && t0.n > 0) {
+      if (SX <= 2 && t0.n > 0) {
         const float4* pp = reinterpret_cast<const float4*>(smem + L::o_pos + (s & 1) * 512);
         const float4 ps = pp[j], pd = pp[16 + j];
         const int slot = (j >= t0.n0 && j < t0.n) ? t0.sl1 : t0.sl0;
@@ -764,7 +776,7 @@ __device__ __forceinline__ void ws_run(const WsArgs& A, unsigned char* smem) {
         // once would need 240 registers), then the folds
         static_assert(T0 == 6, "two scalar-type tiles per wave 0, 1, 2");
 #pragma unroll
-        for (int t2 = 2 * W; t2 < 2 * W + 2; t2 += 2) {
+        for (int t2 = 2 * SX; t2 < 2 * SX + 2; t2 += 2) {
           f32x4 u0[2], u1[3][2], u2[5][2], wv[2];
 #pragma unroll
           for (int k = 0; k < 2; ++k) {
@@ -793,7 +805,7 @@ __device__ __forceinline__ void ws_run(const WsArgs& A, unsigned char* smem) {
           __builtin_amdgcn_sched_barrier(0);
         }
         // (wave 2) the table row of edge j: lane group 0 writes the harmonics, group k the k-th dense coupling
-        if constexpr (W == 2) {
+        if constexpr (SX == 2) {
         float* zr = reinterpret_cast<float*>(smem + L::o_zt + (s & 1) * 16 * L::ZT * 4) + j * L::ZT;
         auto store_dense = [&](auto atag, auto btag, auto ctag, float* dstp) {
           constexpr int A1 = decltype(atag)::value, B1 = decltype(btag)::value, C1 = decltype(ctag)::value;
@@ -951,9 +963,9 @@ __device__ __forceinline__ void ws_run(const WsArgs& A, unsigned char* smem) {
           if (lane < 16) reinterpret_cast<float*>(smem + L::o_srow)[(s & 1) * 16 + lane] = srow;
         }
       }
-      if constexpr (W == 3) ws_wait_vm0();  // the copies of phase X have landed before the barrier that publishes them
-    } else if constexpr (ROLE < 2) {
-      // ---- waves 4 / 5: run sums of tile s - 1 (out tile rows -> at most two runs per column) ----
+      if constexpr (SX == 3) ws_wait_vm0();  // the cutter's copies of phase X have landed before the barrier that publishes them
+    } else if constexpr (RSW) {
+      // ---- run sums of tile s - 1 (out tile rows -> at most two runs per column) ----
       if (t1.n > 0) {
         const float* op = reinterpret_cast<const float*>(smem + L::o_o) + lane;
         float s0[NQW], s1[NQW];
@@ -993,7 +1005,7 @@ __device__ __forceinline__ void ws_run(const WsArgs& A, unsigned char* smem) {
     } else {
       // ---- waves 6 / 7: copies of the h[src] rows of tile s + 1 (the image is free: phase X has read tile s); they have
       //      landed before the barrier that ends this phase ----
-      if (ids_requested(s + 1)) gather_part(s + 1, ROLE - 2);
+      if (ids_requested(s + 1)) gather_part(s + 1, SY - 2);
       ws_wait_vm0();
     }
     if constexpr (!TEAM1) __builtin_amdgcn_s_setprio(0);
