@@ -251,6 +251,9 @@ __device__ __forceinline__ void ws_load_w(const float* packed, const int prod /*
 #ifndef WS_XROT
 #define WS_XROT 2   // measured 19.43 -> 19.00 ms per launch pair (1: 19.24, 3: 19.38)
 #endif
+#ifndef WS_INITMAP
+#define WS_INITMAP 0
+#endif
 #ifndef WS_YROT
 #define WS_YROT 0
 #endif
@@ -493,6 +496,10 @@ __device__ __forceinline__ void ws_run(const WsArgs& A, unsigned char* smem) {
   // vector-heavy jobs -- share their SIMDs with the lighter roles of product #2 (l3 = 1 tiles: waves 6, 7), not with the
   // l3 = 2 roles (waves 4, 5), which are the longest of phase X
   constexpr int SX = TEAM1 ? -1 : ((W + WS_XROT) & 3);
+  // scalar-type tiles whose initial values this wave computes (two at a time): WS_INITMAP 0: two tiles on each of the jobs
+  // 0-2; 1: four on the cutter's wave (the shortest job), two on the table's wave, none on the conversion waves (the longest)
+  constexpr int ITB = SX < 0 ? 0 : (WS_INITMAP ? (SX == 3 ? 0 : 4) : 2 * SX);
+  constexpr int ITE = SX < 0 ? 0 : (WS_INITMAP ? (SX == 3 ? 4 : (SX == 2 ? 6 : 4)) : (SX <= 2 ? 2 * SX + 2 : 2 * SX));
   constexpr int SY = TEAM1 ? ((W + WS_YROT) & 3) : -1;  // phase Y jobs of team 1: 0 / 1 run sums, 2 / 3 row copies
   using O = Own<LMAX, TT, ROLE>;
   using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
@@ -691,9 +698,8 @@ __device__ __forceinline__ void ws_run(const WsArgs& A, unsigned char* smem) {
     WS_STAMP(3)
     WS_PM0
     // =========================================== phase X ===========================================
-    if constexpr (SX == 3) {
-      cut(s + 1);
-    } else if constexpr (!TEAM1) {
+    if constexpr (SX == 3) cut(s + 1);
+    if constexpr (!TEAM1) {
       // ---- gathered rows of tile s -> B fragments of product #1.  Wave p (0, 1) converts rows 8 p .. 8 p + 7 of every
       //      degree: lane = (row j8, channel group g, half pc) handles ONE piece (4 channels x all components) per degree,
       //      i.e. half of a fragment lane's 8 k slots -> 8-byte stores of the hi and the lo halves ----
@@ -759,7 +765,7 @@ __device__ __forceinline__ void ws_run(const WsArgs& A, unsigned char* smem) {
       // ---- wave 2: the edge table of tile s (harmonics, distance, dense couplings); waves 0-2: the initial values of the
       //      scalar-type tiles of product #1 (two tiles each): pre-mix of (0, 0, 0) + d-term + the pre-mix of the feature-first paths folded with their
       //      couplings -- all of it used to be recomputed / folded by the four product waves ----
-      if (SX <= 2 && t0.n > 0) {
+      if (ITB < ITE && t0.n > 0) {
         const float4* pp = reinterpret_cast<const float4*>(smem + L::o_pos + (s & 1) * 512);
         const float4 ps = pp[j], pd = pp[16 + j];
         const int slot = (j >= t0.n0 && j < t0.n) ? t0.sl1 : t0.sl0;
@@ -776,7 +782,7 @@ __device__ __forceinline__ void ws_run(const WsArgs& A, unsigned char* smem) {
         // once would need 240 registers), then the folds
         static_assert(T0 == 6, "two scalar-type tiles per wave 0, 1, 2");
 #pragma unroll
-        for (int t2 = 2 * SX; t2 < 2 * SX + 2; t2 += 2) {
+        for (int t2 = ITB; t2 < ITE; t2 += 2) {
           f32x4 u0[2], u1[3][2], u2[5][2], wv[2];
 #pragma unroll
           for (int k = 0; k < 2; ++k) {
