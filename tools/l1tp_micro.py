@@ -50,3 +50,25 @@ for H in a.H:
             ref = o.clone()
         print(f"{ir} -> {a.out or ir}  B={a.B} kernel={k}: {ms:.3f} ms  {a.B / ms / 1e6:.1f} Grows/s*1e-3  "
               f"{gb / ms * 1e3:.0f} GB/s algorithmic  diff-vs-first {err:.1e}", flush=True)
+    # forward + backward (grad_in1 and grad_W; in2 = harmonics of fixed positions needs none): the training use of the operator
+    mod.kernel = 0
+    xg = x.clone().requires_grad_(True)
+    go = torch.randn(a.B, Dout, device=dev)
+
+    def fb():
+        for p in mod.parameters():
+            p.grad = None
+        xg.grad = None
+        mod(xg, y).backward(go)
+
+    fb(); fb()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(max(1, a.iters // 2)):
+        fb()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / max(1, a.iters // 2)
+    print(f"{ir} -> {a.out or ir}  B={a.B} forward + backward (grad_in1, grad_W): {ms:.3f} ms  "
+          f"{a.B / ms / 1e6:.2f} Grows/s*1e-3", flush=True)
