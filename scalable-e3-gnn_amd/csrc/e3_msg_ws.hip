@@ -251,6 +251,9 @@ __device__ __forceinline__ void ws_load_w(const float* packed, const int prod /*
 #ifndef WS_XROT
 #define WS_XROT 2   // measured 19.43 -> 19.00 ms per launch pair (1: 19.24, 3: 19.38)
 #endif
+#ifndef WS_NREG
+#define WS_NREG 1
+#endif
 #ifndef WS_INITMAP
 #define WS_INITMAP 0
 #endif
@@ -530,6 +533,21 @@ __device__ __forceinline__ void ws_run(const WsArgs& A, unsigned char* smem) {
   // otherwise hipcc places counted vmcnt waits for them at their first uses INSIDE the loop, where the counter also holds
   // this wave's copies / atomics
   wait_vm0();
+  // per-column norms of this wave's output tiles: they do not change from tile to tile, so they live in registers (WS_NREG;
+  // read from the LDS table in the epilogue, each read sat with its latency exposed right in front of its use: ~6 round trips
+  // per product)
+  f32x4 nrS = {0.f, 0.f, 0.f, 0.f}, nrG = {0.f, 0.f, 0.f, 0.f}, nrV[5];
+  {
+    const f32x4* ntq = reinterpret_cast<const f32x4*>(TEAM1 ? n2tab : n1tab) + g;
+    if constexpr (O::tS >= 0) nrS = ntq[4 * O::tS];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) nrV[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (O::LV > 0) {
+      nrG = ntq[4 * O::tG];
+#pragma unroll
+      for (int c = 0; c < 2 * O::LV + 1; ++c) nrV[c] = ntq[4 * (G::slot0(O::LV) + (2 * O::LV + 1) * O::t + c)];
+    }
+  }
 
   // ---- the tile stream of this workgroup: the XCD group (blockIdx & 7) owns one contiguous eighth of the edges, cut into
   //      chunks of `chunk` edges that the group's workgroups take round-robin (they sweep one neighbourhood of the Morton
@@ -856,7 +874,7 @@ __device__ __forceinline__ void ws_run(const WsArgs& A, unsigned char* smem) {
         const f32x4* nt = reinterpret_cast<const f32x4*>(n2tab) + g;
         float* orow = reinterpret_cast<float*>(smem + L::o_o) + j * L::RS;
         if constexpr (O::tS >= 0) {
-          const f32x4 nv = nt[4 * O::tS];
+          const f32x4 nv = WS_NREG ? nrS : nt[4 * O::tS];
           f32x4 o;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -867,14 +885,14 @@ __device__ __forceinline__ void ws_run(const WsArgs& A, unsigned char* smem) {
         }
         if constexpr (O::LV > 0) {  // a lane's 4 channels x (2l+1) components are contiguous in the output row
           constexpr int Dc = 2 * O::LV + 1;
-          const f32x4 gn = nt[4 * O::tG];
+          const f32x4 gn = WS_NREG ? nrG : nt[4 * O::tG];
           f32x4 gt;
 #pragma unroll
           for (int r = 0; r < 4; ++r) gt[r] = sigmoid_(accG[r] * gn[r] * isrow) * isrow;
           float o[4 * Dc];
 #pragma unroll
           for (int c = 0; c < Dc; ++c) {
-            const f32x4 nv = nt[4 * (G::slot0(O::LV) + Dc * O::t + c)];
+            const f32x4 nv = WS_NREG ? nrV[c] : nt[4 * (G::slot0(O::LV) + Dc * O::t + c)];
             f32x4 oc;
             if constexpr (!IO16 && (WS_PKT & 4)) {
               oc = accV[c] * nv * gt;  // whole-vector products: v_pk_mul_f32
@@ -923,7 +941,7 @@ __device__ __forceinline__ void ws_run(const WsArgs& A, unsigned char* smem) {
         unsigned char* b2 = smem + L::o_b2 + lane * 16 + 8 * O::t;
         auto put4 = [&](const int fr, const float (&f)[4]) { ws_put4<IO16>(b2 + fr * L::FRB, f, srow); };
         if constexpr (O::tS >= 0) {
-          const f32x4 nv = nt[4 * O::tS];
+          const f32x4 nv = WS_NREG ? nrS : nt[4 * O::tS];
           float f[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -934,7 +952,7 @@ __device__ __forceinline__ void ws_run(const WsArgs& A, unsigned char* smem) {
         }
         if constexpr (O::LV > 0) {
           constexpr int Dc = 2 * O::LV + 1;
-          const f32x4 gn = nt[4 * O::tG];
+          const f32x4 gn = WS_NREG ? nrG : nt[4 * O::tG];
           f32x4 gt;
 #pragma unroll
           for (int r = 0; r < 4; ++r) gt[r] = sigmoid_(accG[r] * gn[r]);
@@ -946,7 +964,7 @@ __device__ __forceinline__ void ws_run(const WsArgs& A, unsigned char* smem) {
           f32x4 fsv = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int c = 0; c < Dc; ++c) {
-            const f32x4 nv = nt[4 * (G::slot0(O::LV) + Dc * O::t + c)];
+            const f32x4 nv = WS_NREG ? nrV[c] : nt[4 * (G::slot0(O::LV) + Dc * O::t + c)];
             f32x4 fv;
             if constexpr (!IO16 && (WS_PKT & 8)) {
               fv = accV[c] * nv * gt;  // whole-vector products / fma: v_pk_mul_f32, v_pk_fma_f32
