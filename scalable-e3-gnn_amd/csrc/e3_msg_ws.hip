@@ -254,6 +254,9 @@ __device__ __forceinline__ void ws_load_w(const float* packed, const int prod /*
 #ifndef WS_NREG
 #define WS_NREG 1
 #endif
+#ifndef WS_PRIO1
+#define WS_PRIO1 WS_PRIO   // product #1 (phase Y: its partners have slack)
+#endif
 #ifndef WS_INITMAP
 #define WS_INITMAP 0
 #endif
@@ -926,7 +929,7 @@ __device__ __forceinline__ void ws_run(const WsArgs& A, unsigned char* smem) {
         const int slot = (j >= t0.n0 && j < t0.n) ? t0.sl1 : t0.sl0;
         const float* urow = reinterpret_cast<const float*>(smem + L::o_u + slot * L::U_ROW) + 4 * g;
         f32x4 accV[5], accG, accS;
-        __builtin_amdgcn_s_setprio(WS_PRIO);
+        __builtin_amdgcn_s_setprio(WS_PRIO1);
         WS_PM(5)
         ws_tp<LMAX, TT, ROLE, true, IO16>(w, smem + L::o_b1 + lane * 16, ztr, urow, wdtab + 4 * g,
                                           reinterpret_cast<const f32x4*>(smem + L::o_init) + lane, accV, accG, accS, y, tpmk);
