@@ -66,7 +66,7 @@ __device__ unsigned long long g_ws_tp[8][8];   // per wave: cycles to the marks 
 template <int LMAX, int TT, bool IO16>
 struct Ws {
   using G = MsgGeom<LMAX, TT>;
-  static_assert(TT == 2 && LMAX == 2, "instantiated for H = 32, l_max = 2");
+  static_assert(TT == 2 && (LMAX == 1 || LMAX == 2), "instantiated for H = 32, l_max = 1 / 2");
   static constexpr int H = G::H, D = G::D, NS = G::NS, UD = G::UD;
   static constexpr int ES = IO16 ? 2 : 4;                  // bytes per stored feature element
   static constexpr int NC = (LMAX + 1) * (LMAX + 1);       // components of a feature row
@@ -76,7 +76,7 @@ struct Ws {
   static constexpr int frag_ff(int l) { return NC + l - 1; }
   // gathered rows: region A = [1o | 2e] (8 H elements per row, one row per copy, rows padded by 16 bytes so that the 16-byte
   // column reads of the 16 rows fall on different banks), region B = [0e] rows, linear (8 or 16 rows per copy)
-  static constexpr int GA_ROW = 8 * H * ES;
+  static constexpr int GA_ROW = (NC - 1) * H * ES;         // [1o | 2e] (l_max = 1: [1o])
   static constexpr int GA_STRIDE = GA_ROW + 16;
   static constexpr int GA_BYTES = 16 * GA_STRIDE;
   static constexpr int GB_ROW = H * ES;
@@ -97,7 +97,7 @@ struct Ws {
   // edge table (ring of 2 tiles x 16 edges x ZT floats): harmonics, distance and the dense couplings z[a][c] = sum_b C[a][b][c] Y[b]
   // of the four paths whose coupling is not a multiple of one harmonic -- computed ONCE per tile by wave 2 and read by the four
   // waves of both products (each of them used to recompute its paths' couplings: ~80 vector instructions per wave and product)
-  static constexpr int z_y = 0, z_112 = 12, z_121 = 28, z_211 = 40, z_222 = 56, ZT = 84;
+  static constexpr int z_y = 0, z_112 = 12, z_121 = 28, z_211 = 40, z_222 = 56, ZT = LMAX == 2 ? 84 : 12;
   static constexpr int o_zt = o_srow + 2 * 64;
   static constexpr int o_init = o_zt + 2 * 16 * ZT * 4;                 // initial values of the T(0) scalar-type tiles of product #1
   static constexpr int o_g = o_init + G::T(0) * 1024;                   // gather image (copied in phase Y, read in phase X)
@@ -257,6 +257,9 @@ __device__ __forceinline__ void ws_load_w(const float* packed, const int prod /*
 #ifndef WS_PRIO1
 #define WS_PRIO1 WS_PRIO   // product #1 (phase Y: its partners have slack)
 #endif
+#ifndef WS_LMAX1
+#define WS_LMAX1 0   // 1: also instantiate the kernel for l_max = 1 (correct, but 10.0 vs 6.4 ms per launch pair against the one-wave-per-tile kernel: the phase structure does not pay for so little work per edge)
+#endif
 #ifndef WS_INITMAP
 #define WS_INITMAP 0
 #endif
@@ -300,7 +303,6 @@ struct TpRun {
   using IT = TpItems<LMAX>;
   static constexpr int LV = O::LV, t = O::t, tG = O::tG, tS = O::tS;
   static constexpr bool SC = tG >= 0 || tS >= 0;  // owns scalar-type (l3 = 0) tiles
-  static_assert(LMAX == 2, "edge table layout");
 
   const RoleW<O::NW>& w;
   const unsigned char* bfr;
@@ -505,7 +507,8 @@ __device__ __forceinline__ void ws_run(const WsArgs& A, unsigned char* smem) {
   // scalar-type tiles whose initial values this wave computes (two at a time): WS_INITMAP 0: two tiles on each of the jobs
   // 0-2; 1: four on the cutter's wave (the shortest job), two on the table's wave, none on the conversion waves (the longest)
   constexpr int ITB = SX < 0 ? 0 : (WS_INITMAP ? (SX == 3 ? 0 : 4) : 2 * SX);
-  constexpr int ITE = SX < 0 ? 0 : (WS_INITMAP ? (SX == 3 ? 4 : (SX == 2 ? 6 : 4)) : (SX <= 2 ? 2 * SX + 2 : 2 * SX));
+  constexpr int ITE0 = SX < 0 ? 0 : (WS_INITMAP ? (SX == 3 ? 4 : (SX == 2 ? 6 : 4)) : (SX <= 2 ? 2 * SX + 2 : 2 * SX));
+  constexpr int ITE = ITE0 < G::T(0) ? ITE0 : G::T(0);
   constexpr int SY = TEAM1 ? ((W + WS_YROT) & 3) : -1;  // phase Y jobs of team 1: 0 / 1 run sums, 2 / 3 row copies
   using O = Own<LMAX, TT, ROLE>;
   using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
@@ -567,7 +570,7 @@ __device__ __forceinline__ void ws_run(const WsArgs& A, unsigned char* smem) {
   auto gather_part = [&](const int tile, const int part) {
     const int* ids = reinterpret_cast<const int*>(smem + L::o_ids) + (tile & 3) * 32;
     const uint32_t gb = lds0 + L::o_g;
-    static_assert((L::GA_ROW == 1024 && L::GB_ROW == 128) || (L::GA_ROW == 512 && L::GB_ROW == 64), "copy shapes of the image");
+    static_assert(L::GA_ROW % 16 == 0 && L::GA_ROW <= 1024 && (L::GB_ROW == 128 || L::GB_ROW == 64), "copy shapes of the image");
     constexpr int LA = L::GA_ROW / 16;          // lanes of one region-A row copy (64 fp32, 32 bf16)
     constexpr int UPR = L::GB_ROW / 16;         // 16-byte units per [0e] row (8 / 4)
     constexpr int RPC = 64 / UPR;               // [0e] rows per copy (8: one piece per part / 16: part 0 copies them all)
@@ -733,12 +736,12 @@ __device__ __forceinline__ void ws_run(const WsArgs& A, unsigned char* smem) {
         const float4 ps = pp[row], pd = pp[16 + row];
         float q2[20], q1[12], q0[4];
         {
-          const unsigned char* r2 = gimg + row * L::GA_STRIDE + (3 * H + (16 * pc + 4 * gg) * 5) * ES;
+          const unsigned char* r2 = gimg + row * L::GA_STRIDE + (LMAX == 2 ? (3 * H + (16 * pc + 4 * gg) * 5) * ES : 0);
           const unsigned char* r1 = gimg + row * L::GA_STRIDE + (16 * pc + 4 * gg) * 3 * ES;
           const unsigned char* r0 = gimg + L::GA_BYTES + row * L::GB_ROW + (16 * pc + 4 * gg) * ES;
           if constexpr (!IO16) {
 #pragma unroll
-            for (int u = 0; u < 5; ++u) { const f32x4 v = reinterpret_cast<const f32x4*>(r2)[u]; q2[4 * u] = v[0]; q2[4 * u + 1] = v[1]; q2[4 * u + 2] = v[2]; q2[4 * u + 3] = v[3]; }
+            for (int u = 0; u < (LMAX == 2 ? 5 : 0); ++u) { const f32x4 v = reinterpret_cast<const f32x4*>(r2)[u]; q2[4 * u] = v[0]; q2[4 * u + 1] = v[1]; q2[4 * u + 2] = v[2]; q2[4 * u + 3] = v[3]; }
 #pragma unroll
             for (int u = 0; u < 3; ++u) { const f32x4 v = reinterpret_cast<const f32x4*>(r1)[u]; q1[4 * u] = v[0]; q1[4 * u + 1] = v[1]; q1[4 * u + 2] = v[2]; q1[4 * u + 3] = v[3]; }
             { const f32x4 v = reinterpret_cast<const f32x4*>(r0)[0]; q0[0] = v[0]; q0[1] = v[1]; q0[2] = v[2]; q0[3] = v[3]; }
@@ -748,7 +751,7 @@ __device__ __forceinline__ void ws_run(const WsArgs& A, unsigned char* smem) {
               o[2] = __builtin_bit_cast(float, v.y << 16); o[3] = __builtin_bit_cast(float, v.y & 0xffff0000u);
             };
 #pragma unroll
-            for (int u = 0; u < 5; ++u) widen(reinterpret_cast<const uint2*>(r2)[u], q2 + 4 * u);
+            for (int u = 0; u < (LMAX == 2 ? 5 : 0); ++u) widen(reinterpret_cast<const uint2*>(r2)[u], q2 + 4 * u);
 #pragma unroll
             for (int u = 0; u < 3; ++u) widen(reinterpret_cast<const uint2*>(r1)[u], q1 + 4 * u);
             widen(reinterpret_cast<const uint2*>(r0)[0], q0);
@@ -779,14 +782,14 @@ __device__ __forceinline__ void ws_run(const WsArgs& A, unsigned char* smem) {
             put4(L::frag_ff(L1), f);
           }
         };
-        degree(I2{}, q2);
+        if constexpr (LMAX == 2) degree(I2{}, q2);
         degree(I1{}, q1);
         degree(I0{}, q0);
       }
       // ---- wave 2: the edge table of tile s (harmonics, distance, dense couplings); waves 0-2: the initial values of the
       //      scalar-type tiles of product #1 (two tiles each): pre-mix of (0, 0, 0) + d-term + the pre-mix of the feature-first paths folded with their
       //      couplings -- all of it used to be recomputed / folded by the four product waves ----
-      if (ITB < ITE && t0.n > 0) {
+      if ((ITB < ITE || SX == 2) && t0.n > 0) {
         const float4* pp = reinterpret_cast<const float4*>(smem + L::o_pos + (s & 1) * 512);
         const float4 ps = pp[j], pd = pp[16 + j];
         const int slot = (j >= t0.n0 && j < t0.n) ? t0.sl1 : t0.sl0;
@@ -797,11 +800,11 @@ __device__ __forceinline__ void ws_run(const WsArgs& A, unsigned char* smem) {
         const float dsc = dist * xs;
         float z110[3][1], z220[5][1];
         make_z<1, 1, 0>(y, z110);
-        make_z<2, 2, 0>(y, z220);
+        if constexpr (LMAX == 2) make_z<2, 2, 0>(y, z220);
         f32x4* ip = reinterpret_cast<f32x4*>(smem + L::o_init) + lane;
         // two tiles at a time: their 20 pre-mix reads first (this wave also holds its product weights: all T(0) tiles at
         // once would need 240 registers), then the folds
-        static_assert(T0 == 6, "two scalar-type tiles per wave 0, 1, 2");
+        static_assert(T0 == 6 || T0 == 4, "two scalar-type tiles per wave (0, 1, 2 / 0, 1)");
 #pragma unroll
         for (int t2 = ITB; t2 < ITE; t2 += 2) {
           f32x4 u0[2], u1[3][2], u2[5][2], wv[2];
@@ -812,8 +815,10 @@ __device__ __forceinline__ void ws_run(const WsArgs& A, unsigned char* smem) {
             wv[k] = *reinterpret_cast<const f32x4*>(wdtab + 4 * g + G::wdoff(0) + tt * 16);
 #pragma unroll
             for (int a = 0; a < 3; ++a) u1[a][k] = *reinterpret_cast<const f32x4*>(urow + G::uoff(1, 1, 0) + (a * T0 + tt) * 16);
+            if constexpr (LMAX == 2) {
 #pragma unroll
-            for (int a = 0; a < 5; ++a) u2[a][k] = *reinterpret_cast<const f32x4*>(urow + G::uoff(2, 2, 0) + (a * T0 + tt) * 16);
+              for (int a = 0; a < 5; ++a) u2[a][k] = *reinterpret_cast<const f32x4*>(urow + G::uoff(2, 2, 0) + (a * T0 + tt) * 16);
+            }
           }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -824,8 +829,10 @@ __device__ __forceinline__ void ws_run(const WsArgs& A, unsigned char* smem) {
               v[r] = __builtin_fmaf(wv[k][r], dsc, v[r]);
 #pragma unroll
               for (int a = 0; a < 3; ++a) v[r] = __builtin_fmaf(u1[a][k][r], z110[a][0], v[r]);
+              if constexpr (LMAX == 2) {
 #pragma unroll
-              for (int a = 0; a < 5; ++a) v[r] = __builtin_fmaf(u2[a][k][r], z220[a][0], v[r]);
+                for (int a = 0; a < 5; ++a) v[r] = __builtin_fmaf(u2[a][k][r], z220[a][0], v[r]);
+              }
             }
             ip[64 * (t2 + k)] = v;
           }
@@ -850,13 +857,15 @@ __device__ __forceinline__ void ws_run(const WsArgs& A, unsigned char* smem) {
           *reinterpret_cast<f32x4*>(zr + L::z_y) = f32x4{y[0], y[1], y[2], y[3]};
           *reinterpret_cast<f32x4*>(zr + L::z_y + 4) = f32x4{y[4], y[5], y[6], y[7]};
           *reinterpret_cast<f32x4*>(zr + L::z_y + 8) = f32x4{y[8], dsc, 0.f, 0.f};
-          store_dense(I1{}, I1{}, I2{}, zr + L::z_112);
-        } else if (g == 1) {
-          store_dense(I1{}, I2{}, I1{}, zr + L::z_121);
-        } else if (g == 2) {
-          store_dense(I2{}, I1{}, I1{}, zr + L::z_211);
-        } else {
-          store_dense(I2{}, I2{}, I2{}, zr + L::z_222);
+          if constexpr (LMAX == 2) store_dense(I1{}, I1{}, I2{}, zr + L::z_112);
+        } else if constexpr (LMAX == 2) {
+          if (g == 1) {
+            store_dense(I1{}, I2{}, I1{}, zr + L::z_121);
+          } else if (g == 2) {
+            store_dense(I2{}, I1{}, I1{}, zr + L::z_211);
+          } else {
+            store_dense(I2{}, I2{}, I2{}, zr + L::z_222);
+          }
         }
         }
       }
@@ -1088,7 +1097,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 // host
 // ------------------------------------------------------------------------------------------------------------------
 bool msg_ws_supported(int lmax, int hidden, int dtype) {
-  return lmax == 2 && hidden == 32 && (dtype == E3_F32 || dtype == E3_BF16);
+  return (lmax == 2 || (lmax == 1 && WS_LMAX1)) && hidden == 32 && (dtype == E3_F32 || dtype == E3_BF16);
 }
 
 int msg_ws_launch(int lmax, int hidden, int dtype, const void* h, int64_t ldh, int64_t N, const float* pos4, const int32_t* src,
@@ -1097,29 +1106,38 @@ int msg_ws_launch(int lmax, int hidden, int dtype, const void* h, int64_t ldh, i
   if (!msg_ws_supported(lmax, hidden, dtype)) return E3_ERR_UNSUPPORTED;
   if (E > 0x7fffffffLL - 65536) return E3_ERR_UNSUPPORTED;  // 32-bit edge arithmetic with chunk head room
   const int io = dtype == E3_BF16 ? 1 : 0;
+  const int li = lmax == 2 ? 1 : 0;
+#if WS_LMAX1
+  const void* kern = li ? (io ? (const void*)msg_ws_kernel<2, 2, true> : (const void*)msg_ws_kernel<2, 2, false>)
+                        : (io ? (const void*)msg_ws_kernel<1, 2, true> : (const void*)msg_ws_kernel<1, 2, false>);
+  const int lds = li ? (io ? Ws<2, 2, true>::total : Ws<2, 2, false>::total) : (io ? Ws<1, 2, true>::total : Ws<1, 2, false>::total);
+  const int ud = li ? MsgGeom<2, 2>::UD : MsgGeom<1, 2>::UD;
+#else
   const void* kern = io ? (const void*)msg_ws_kernel<2, 2, true> : (const void*)msg_ws_kernel<2, 2, false>;
   const int lds = io ? Ws<2, 2, true>::total : Ws<2, 2, false>::total;
+  const int ud = MsgGeom<2, 2>::UD;
+#endif
   int dev = 0;
   E3_HIP_CHECK(hipGetDevice(&dev));
   static std::mutex mu;
-  static int cus_of[64][2];
+  static int cus_of[64][2][2];
   int cus = 0;
   {
     std::lock_guard<std::mutex> lock(mu);
     if (dev < 0 || dev >= 64) return E3_ERR_INVALID_ARG;
-    if (cus_of[dev][io] == 0) {  // once per device and storage type: the kernel needs its LDS image admitted
+    if (cus_of[dev][io][li] == 0) {  // once per device and storage type: the kernel needs its LDS image admitted
       E3_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
       int n = 0;
       if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-      cus_of[dev][io] = n;
+      cus_of[dev][io][li] = n;
     }
-    cus = cus_of[dev][io];
+    cus = cus_of[dev][io][li];
   }
   int chunk = chunk_edges > 0 ? (chunk_edges + 15) / 16 * 16 : 256;
   const int64_t nchunks = (E + chunk - 1) / chunk;
   int nwg = (int)std::min<int64_t>(cus, nchunks);  // one workgroup of 8 waves per CU
   nwg = std::max(8, (nwg + 7) / 8 * 8);
-  const float* hmax = premix + (size_t)N * MsgGeom<2, 2>::UD;  // per-node row maxima behind the table (e3_msg_premix)
+  const float* hmax = premix + (size_t)N * ud;  // per-node row maxima behind the table (e3_msg_premix)
   WsArgs a = {h, ldh, reinterpret_cast<const float4*>(pos4), src, dst, E, static_cast<const float*>(packed), premix, hmax,
               in_scale, out, ldo, chunk};
   void* args[] = {&a};
