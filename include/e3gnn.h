@@ -284,6 +284,13 @@ int e3_tp_backward(const e3_tp_plan* plan, const void* in1, int64_t ld_in1, cons
  * has no weights (t).  grad_in2 follows e3_tp_backward's convention (accumulation dtype; broadcast in2: ld_in2 == 0,
  * ld_gin2 == 0 and a zero-filled [in2_dim] row, summed with atomics).  Either pointer array of _operands may be null.
  */
+/* grad_weights alone, fused (fp32): the features and the normalised output gradient of a row tile are built in LDS and
+ * contracted on v_mfma_f32_32x32x2_f32 -- nothing of size [B, D3, rows] reaches HBM.  grad_weights[c]: [rows, cols] fp32,
+ * ZERO-FILLED by the caller (sums arrive through atomics), nullptr to skip a class.  E3_ERR_UNSUPPORTED (nothing launched) when a
+ * requested class has more than 32 output tiles of 32 x 32 or no row tile fits the LDS: use the operand pass + GEMM then. */
+int e3_tp_backward_weights(const e3_tp_plan* plan, const void* in1, int64_t ld_in1, const void* in2, int64_t ld_in2,
+                           const void* packed, const void* grad_out, int64_t ld_gout, void* const grad_weights[6],
+                           int64_t B, int dtype, void* stream);
 int e3_tp_backward_operands(const e3_tp_plan* plan, const void* in1, int64_t ld_in1, const void* in2, int64_t ld_in2,
                             const void* packed, const void* grad_out, int64_t ld_gout, void* const features[6],
                             void* const gout[6], int64_t B, int dtype, void* stream);

@@ -86,6 +86,8 @@ SIGNATURES = {
     "e3_add_pow2_scale": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "e3_tp_backward": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
                                c_int64, c_void_p, c_int64, c_void_p * 6, c_int64, c_int, c_void_p]),
+    "e3_tp_backward_weights": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
+                                       c_int64, c_int, c_void_p]),
     "e3_tp_backward_operands": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
                                         c_void_p, c_int64, c_int, c_void_p]),
     "e3_tp_backward_contract": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p,

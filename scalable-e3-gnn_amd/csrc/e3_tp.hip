@@ -755,6 +755,159 @@ static int tp_launch_bwd_contract(const e3_tp_plan* plan, const void* in1, int64
   return tp_launch_bwd_contract_rw<T, 1>(plan, in1, ld1, in2, ld2, t, gin1, ldg1, gin2, ldg2, B, s);
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Fused weight gradient of one output class (fp32): grad_W[c3][krow][w] += sum_{b,c} F[b,c,krow] G[b,c,w] with the features F and
+// the normalised output gradient G of a row tile built in LDS and contracted on v_mfma_f32_32x32x2_f32 (exact fp32 products) --
+// nothing of size [B, D3, K] reaches HBM.  One workgroup = 4 waves; output tiles of 32 x 32 are dealt to the waves round-robin,
+// their accumulators live in registers over the whole row range of the workgroup and leave through atomics at the end.
+// LDS: x (class order) and y of R rows, Fs [R D3][ldF], Gs [R D3][ldG]; ldF, ldG = 32 (mod 64) floats, so that the two k rows of
+// one MFMA operand read (lanes 0-31 / 32-63) fall on different banks.
+// ---------------------------------------------------------------------------------------------------
+template <typename G>
+__device__ __forceinline__ void tp_wgrad_feat_item(const float* x, const float* y, float* F, int ldF) {
+  if constexpr (G::ok) {
+    float f[G::D3];
+    G::feat(x, y, f);
+#pragma unroll
+    for (int c = 0; c < G::D3; ++c) F[c * ldF] = f[c];
+  }
+}
+
+typedef float tp_f32x16 __attribute__((ext_vector_type(16)));
+
+template <int NTW>
+__global__ __launch_bounds__(256) void tp_wgrad_mfma_kernel(const float* __restrict__ in1, int64_t ld1,
+                                                            const float* __restrict__ in2, int64_t ld2,
+                                                            const float* __restrict__ packed, const float* __restrict__ go,
+                                                            int64_t ldg, float* __restrict__ gw, int c3, int R, int ldF,
+                                                            int ldG, int64_t B, TpDev p) {
+  using A = float;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int l3 = c3 >> 1, D3 = 2 * l3 + 1, K = p.K[c3], M = p.M[c3];
+  float* xs = reinterpret_cast<float*>(smem_raw);
+  float* ys = xs + (size_t)R * p.D1;
+  float* Fs = ys + (((size_t)R * p.Dy + 3) & ~(size_t)3);
+  float* Gs = Fs + (size_t)R * D3 * ldF;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const float* normcol = packed + p.normcol_off;
+  const int tm = (K + 31) / 32, tn = (M + 31) / 32, ntile = tm * tn;
+  tp_f32x16 acc[NTW];
+#pragma unroll
+  for (int t = 0; t < NTW; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  // padding columns are zero for the whole launch (the row passes never write them)
+  for (int i = tid; i < R * D3 * ldF; i += 256) Fs[i] = 0.f;
+  for (int i = tid; i < R * D3 * ldG; i += 256) Gs[i] = 0.f;
+  const int64_t ntiles = (B + R - 1) / R;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {  // uniform trip count per block: barriers are safe
+    const int64_t row0 = tile * R;
+    __syncthreads();
+    // stage x (class order) and y: column outer, eight rows' loads in flight per thread before their LDS stores (a plain element
+    // loop waited for every load in turn: ~30 us per tile)
+    for (int d = tid; d < p.D1; d += 256) {
+      const int cp = p.cpos[d];
+      for (int r0 = 0; r0 < R; r0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = row0 + r0 + u < B ? in1[(row0 + r0 + u) * ld1 + d] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) xs[(r0 + u) * p.D1 + cp] = v[u];
+      }
+    }
+    for (int i = tid; i < R * p.Dy; i += 256) {
+      const int r = i / p.Dy, d = i - r * p.Dy;
+      ys[i] = row0 + r < B ? in2[(row0 + r) * ld2 + d] : 0.f;
+    }
+    __syncthreads();
+    // features of the tile: wave w owns rows w R/4 .. (w + 1) R/4; a path with n channels puts 64 / np2(n) rows side by side in
+    // the 64 lanes (rows past B: x = y = 0 -> zero features)
+    {
+      const int rw = R >> 2, rbase = wave * rw;
+      for (int pi = 0; pi < p.npath[c3]; ++pi) {
+        const TpPath P = p.paths[p.poff[c3] + pi];
+        const int n = p.n[P.c1];
+        int sh = 6;                                   // np2 = 1 << sh >= n, at most 64
+        while (sh > 0 && (1 << (sh - 1)) >= n) --sh;
+        const int np2 = 1 << sh, rpi = 64 >> sh, sub = lane >> sh, k0 = lane & (np2 - 1);
+        for (int rb = 0; rb < rw; rb += rpi) {
+          const int r = rbase + rb + sub;
+          for (int k = k0; k < n; k += np2) {   // (one trip unless n > 64)
+            if (rb + sub < rw) {
+              E3_GRAD_SWITCH(P.l1, P.l2, l3, (tp_wgrad_feat_item<G>(xs + r * p.D1 + p.cbase[P.c1] + k * G::D1,
+                                                                    ys + r * p.Dy + G::D2 / 2 * (G::D2 / 2),
+                                                                    Fs + (size_t)r * G::D3 * ldF + P.wrow + k, ldF)))
+            }
+          }
+        }
+      }
+    }
+    // the output gradient of the whole tile, all threads at once: every thread has several independent loads in flight (row by
+    // row inside the wave loop above, each row waited for its own loads: 26 us per tile)
+    {
+      const int per = D3 * M;   // (c, w) pairs of a row
+      for (int e = tid; e < per; e += 256) {
+        const int c = e / M, w = e - c * M;
+        const int oc = p.ocol[p.ocol_off[c3] + w] + c;
+        const float nv = normcol[oc];
+        for (int r0 = 0; r0 < R; r0 += 8) {
+          float v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = row0 + r0 + u < B ? go[(row0 + r0 + u) * ldg + oc] * nv : 0.f;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) Gs[((size_t)(r0 + u) * D3 + c) * ldG + w] = v[u];
+        }
+      }
+    }
+    __syncthreads();
+    const int kh = lane >> 5, i32 = lane & 31;
+    const int nk = R * D3;  // k rows of this tile (even: R is a multiple of 2)
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+      const int tt = wave + 4 * t;
+      if (tt < ntile) {
+        const int mi = tt / tn, ni = tt - mi * tn;
+        const float* fa = Fs + kh * ldF + 32 * mi + i32;
+        const float* gb = Gs + kh * ldG + 32 * ni + i32;
+        tp_f32x16 a = acc[t];
+        for (int kk = 0; kk < nk; kk += 2) a = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk * ldF], gb[kk * ldG], a, 0, 0, 0);
+        acc[t] = a;
+      }
+    }
+  }
+  // accumulators -> grad_W (C layout of the 32 x 32 MFMA: register r of lane l = C[8 (r >> 2) + 4 (l >> 5) + (r & 3)][l & 31])
+#pragma unroll
+  for (int t = 0; t < NTW; ++t) {
+    const int tt = wave + 4 * t;
+    if (tt < ntile) {
+      const int mi = tt / tn, ni = tt - mi * tn;
+      const int w = 32 * ni + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int krow = 32 * mi + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+        if (krow < K && w < M) atomicAdd(&gw[(size_t)krow * M + w], acc[t][r]);
+      }
+    }
+  }
+}
+
+static int tp_wgrad_geometry(const TpDev& p, int c3, int* R, int* ldF, int* ldG, size_t* lds, int* ntw) {
+  const int D3 = 2 * (c3 >> 1) + 1, K = p.K[c3], M = p.M[c3];
+  if (K <= 0 || M <= 0) return E3_ERR_INVALID_ARG;
+  auto pad = [](int v) { int q = (v + 31) / 32 * 32; return (q % 64 == 32) ? q : q + 32; };
+  *ldF = pad(K);
+  *ldG = pad(M);
+  const int ntile = ((K + 31) / 32) * ((M + 31) / 32);
+  *ntw = (ntile + 3) / 4;
+  if (*ntw > 8) return E3_ERR_UNSUPPORTED;
+  for (int r : {32, 16, 8}) {
+    const size_t need = ((size_t)r * p.D1 + (((size_t)r * p.Dy + 3) & ~(size_t)3) + (size_t)r * D3 * (*ldF + *ldG)) * sizeof(float);
+    if (need <= 150 * 1024) { *R = r; *lds = need; return E3_OK; }
+  }
+  return E3_ERR_UNSUPPORTED;
+}
+
 }  // namespace e3
 
 using namespace e3;
@@ -1040,6 +1193,43 @@ int e3_tp_backward_contract(const e3_tp_plan* plan, const void* in1, int64_t ld1
   hipStream_t s = (hipStream_t)stream;
   return dtype == E3_F32 ? tp_launch_bwd_contract<float>(plan, in1, ld1, in2, ld2, t, grad_in1, ldg1, grad_in2, ldg2, B, s)
                          : tp_launch_bwd_contract<double>(plan, in1, ld1, in2, ld2, t, grad_in1, ldg1, grad_in2, ldg2, B, s);
+}
+
+int e3_tp_backward_weights(const e3_tp_plan* plan, const void* in1, int64_t ld1, const void* in2, int64_t ld2,
+                           const void* packed, const void* grad_out, int64_t ldg, void* const grad_weights[6], int64_t B,
+                           int dtype, void* stream) {
+  if (!plan || B < 0 || !grad_weights) return E3_ERR_INVALID_ARG;
+  if (dtype != E3_F32) return E3_ERR_UNSUPPORTED;
+  if (B == 0) return E3_OK;
+  if (!in1 || !in2 || !packed || !grad_out) return E3_ERR_INVALID_ARG;
+  if (ld1 < plan->dev.D1 || ldg < plan->dev.Dout || (ld2 != 0 && ld2 < plan->dev.Dy)) return E3_ERR_INVALID_ARG;
+  int st = tp_ensure_device(plan);
+  if (st != E3_OK) return st;
+  const TpDev& p = plan->dev;
+  hipStream_t s = (hipStream_t)stream;
+  // every requested class must have a kernel before anything is launched (the caller falls back as a whole)
+  int R[6], ldF[6], ldG[6], ntw[6];
+  size_t lds[6];
+  for (int c = 0; c < 6; ++c) {
+    if (!grad_weights[c]) continue;
+    st = tp_wgrad_geometry(p, c, &R[c], &ldF[c], &ldG[c], &lds[c], &ntw[c]);
+    if (st != E3_OK) return st;
+  }
+  for (int c = 0; c < 6; ++c) {
+    if (!grad_weights[c]) continue;
+    const void* k = ntw[c] <= 2 ? (const void*)tp_wgrad_mfma_kernel<2> : ntw[c] <= 4 ? (const void*)tp_wgrad_mfma_kernel<4>
+                  : ntw[c] <= 6 ? (const void*)tp_wgrad_mfma_kernel<6> : (const void*)tp_wgrad_mfma_kernel<8>;
+    E3_HIP_CHECK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds[c]));
+    const int64_t ntiles = (B + R[c] - 1) / R[c];
+    const int grid = (int)std::min<int64_t>(ntiles, 256 * (lds[c] <= 75 * 1024 ? 2 : 1));
+    const float* a1 = (const float*)in1; const float* a2 = (const float*)in2; const float* pk = (const float*)packed;
+    const float* g = (const float*)grad_out; float* gw = (float*)grad_weights[c];
+    int cc = c, r = R[c], lf = ldF[c], lg = ldG[c];
+    TpDev pd = p;
+    void* args[] = {&a1, &ld1, &a2, &ld2, &pk, &g, &ldg, &gw, &cc, &r, &lf, &lg, &B, &pd};
+    if (hipLaunchKernel(k, dim3(grid), dim3(256), args, lds[c], s) != hipSuccess) return E3_ERR_HIP;
+  }
+  return E3_OK;
 }
 
 const char* e3_tp_last_fused_kernel(void) { return fast_last_kernel(); }

@@ -233,6 +233,10 @@ _BWD_GEMM_MIN_ROWS = 512
 
 
 _WGRAD_SLAB = 4096
+# True: grad_W alone through e3_tp_backward_weights (features in LDS + fp32 MFMA, nothing of size [B, D3, K] in HBM).  Correct
+# (tests/test_tp_backward_gpu.py compares both), but not yet faster: its row tiles wait for their staging loads (150 vs 134 ms
+# for the 100 k-particle forward + backward), so the operand pass + batched GEMM stays the default
+_BWD_FUSED_WGRAD = False
 
 
 def _wgrad_accumulate(gw, F, G):
@@ -285,6 +289,15 @@ def tp_backward(plan: "TPPlan", packed, in1, in2, grad_out, weights, need1, need
                                           ptr(g2), 0 if (g2 is None or bcast) else g2.stride(0), P6(*map(ptr, gws)), B, code,
                                           stream), "e3_tp_backward")
             return g1, g2, gws
+        if not need1 and not need2 and dt == torch.float32 and not bcast and _BWD_FUSED_WGRAD:
+            # grad_W alone (the pinned operator's training case: grad_in1 comes from the transposed operator): features and
+            # output gradient of a row tile built in LDS, contracted on the fp32 MFMA -- no [B, D3, K] operands in HBM
+            st = lib.e3_tp_backward_weights(h, in1.data_ptr(), in1.stride(0), in2.data_ptr(), ld2, packed.data_ptr(),
+                                            grad_out.data_ptr(), grad_out.stride(0), P6(*map(ptr, gws)), B, code, stream)
+            if st == 0:
+                return g1, g2, gws
+            if st != 4:   # anything but E3_ERR_UNSUPPORTED (shape too large for the kernel: the GEMM path below)
+                _lib.check(st, "e3_tp_backward_weights")
         shapes = [tuple(w.shape) if w is not None else None for w in weights]      # (K, M) per class
         per_row = sum((2 * (c >> 1) + 1) * (s[0] + s[1]) for c, s in enumerate(shapes) if s is not None)
         chunk = max(256, min(B, _BWD_WORKSPACE_BYTES // (per_row * (8 if dt == torch.float64 else 4))))

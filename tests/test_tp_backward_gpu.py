@@ -78,3 +78,36 @@ def test_backward_partial_requests_and_empty_batch():
     ye = torch.empty(0, mod.in2_dim, dtype=torch.float64, device=DEV)
     mod(xe, ye).sum().backward()
     assert xe.grad.shape == xe.shape
+
+
+@pytest.mark.parametrize("in1,out,lmax,B", [
+    ("32x0e+32x1o+32x0e+32x1o+1x0e", "32x0e+32x0e+32x1o", 1, 5000),                      # message product #1, l_max = 1
+    ("32x0e+32x1o+32x2e+32x0e+32x1o+32x2e+1x0e", "32x0e+64x0e+32x1o+32x2e", 2, 3001),    # message product #1, l_max = 2
+    ("5x0e+3x0o+7x1o+2x1e", "9x0e+1x0o+4x1e+6x1o", 1, 777),                              # every class, odd sizes
+    ("8x0e+8x1o+8x2e", "8x0e+16x0e+8x1o+8x2e", 2, 33),                                   # fewer rows than one row tile
+])
+def test_fused_weight_gradient_vs_gemm_path(in1, out, lmax, B, monkeypatch):
+    """e3_tp_backward_weights (features in LDS, fp32 MFMA) against the operand pass + GEMM path and the fp64 kernels."""
+    from scalable_e3_gnn_amd import tensor_product as TPM
+    torch.manual_seed(0)
+    mod = SHTensorProduct(in1, out, lmax).to(DEV)
+    mod64 = SHTensorProduct(in1, out, lmax).double().to(DEV)
+    mod64.load_state_dict({k: v.double() for k, v in mod.state_dict().items()})
+    g = torch.Generator(device=DEV).manual_seed(1)
+    x = torch.randn(B, mod.in1_dim, device=DEV, generator=g)
+    y = torch.randn(B, mod.in2_dim, device=DEV, generator=g)
+    go = torch.randn(B, mod.out_dim, device=DEV, generator=g)
+    monkeypatch.setattr(TPM, "_BWD_GEMM_MIN_ROWS", 0)
+    grads = {}
+    for fused in (True, False):
+        monkeypatch.setattr(TPM, "_BWD_FUSED_WGRAD", fused)
+        for p in mod.parameters():
+            p.grad = None
+        mod(x, y).backward(go)
+        grads[fused] = {k: p.grad.clone() for k, p in mod.named_parameters()}
+    mod64(x.double(), y.double()).backward(go.double())
+    for k, p in mod64.named_parameters():
+        ref = p.grad
+        for fused in (True, False):
+            err = float((grads[fused][k].double() - ref).abs().max() / ref.abs().max())
+            assert err < 2e-5, (k, fused, err)
