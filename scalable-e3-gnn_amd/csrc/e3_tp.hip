@@ -901,10 +901,13 @@ static int tp_wgrad_geometry(const TpDev& p, int c3, int* R, int* ldF, int* ldG,
   const int ntile = ((K + 31) / 32) * ((M + 31) / 32);
   *ntw = (ntile + 3) / 4;
   if (*ntw > 8) return E3_ERR_UNSUPPORTED;
-  for (int r : {32, 16, 8}) {
-    const size_t need = ((size_t)r * p.D1 + (((size_t)r * p.Dy + 3) & ~(size_t)3) + (size_t)r * D3 * (*ldF + *ldG)) * sizeof(float);
-    if (need <= 150 * 1024) { *R = r; *lds = need; return E3_OK; }
-  }
+  auto need_of = [&](int r) {
+    return ((size_t)r * p.D1 + (((size_t)r * p.Dy + 3) & ~(size_t)3) + (size_t)r * D3 * (*ldF + *ldG)) * sizeof(float);
+  };
+  // several workgroups per CU hide each other's staging loads: the largest row tile that leaves room for four (then two, then one)
+  for (size_t budget : {(size_t)38 * 1024, (size_t)76 * 1024, (size_t)150 * 1024})
+    for (int r : {32, 16, 8})
+      if (need_of(r) <= budget) { *R = r; *lds = need_of(r); return E3_OK; }
   return E3_ERR_UNSUPPORTED;
 }
 
@@ -1221,7 +1224,8 @@ int e3_tp_backward_weights(const e3_tp_plan* plan, const void* in1, int64_t ld1,
                   : ntw[c] <= 6 ? (const void*)tp_wgrad_mfma_kernel<6> : (const void*)tp_wgrad_mfma_kernel<8>;
     E3_HIP_CHECK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds[c]));
     const int64_t ntiles = (B + R[c] - 1) / R[c];
-    const int grid = (int)std::min<int64_t>(ntiles, 256 * (lds[c] <= 75 * 1024 ? 2 : 1));
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (size_t)(156 * 1024) / lds[c]));
+    const int grid = (int)std::min<int64_t>(ntiles, 256 * per_cu);
     const float* a1 = (const float*)in1; const float* a2 = (const float*)in2; const float* pk = (const float*)packed;
     const float* g = (const float*)grad_out; float* gw = (float*)grad_weights[c];
     int cc = c, r = R[c], lf = ldF[c], lg = ldG[c];

@@ -233,10 +233,10 @@ _BWD_GEMM_MIN_ROWS = 512
 
 
 _WGRAD_SLAB = 4096
-# True: grad_W alone through e3_tp_backward_weights (features in LDS + fp32 MFMA, nothing of size [B, D3, K] in HBM).  Correct
-# (tests/test_tp_backward_gpu.py compares both), but not yet faster: its row tiles wait for their staging loads (150 vs 134 ms
-# for the 100 k-particle forward + backward), so the operand pass + batched GEMM stays the default
-_BWD_FUSED_WGRAD = False
+# grad_W alone (no grad_in1 / grad_in2 wanted from this call) through e3_tp_backward_weights: features in LDS + fp32 MFMA, nothing
+# of size [B, D3, K] in HBM (119 vs 134 ms for the 100 k-particle forward + backward).  False: always the operand pass + batched
+# GEMM (tests/test_tp_backward_gpu.py compares the two)
+_BWD_FUSED_WGRAD = True
 
 
 def _wgrad_accumulate(gw, F, G):
