@@ -7,8 +7,28 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <map>
+#include <mutex>
+#include <utility>
 
 namespace e3 {
+
+// The dynamic-LDS limit of a kernel is a per-device attribute of the function: raise it monotonically under a lock (setting the
+// size of each launch would let two host threads with different plans lower it under each other's launches).
+static int tp_ensure_dyn_lds(const void* fn, size_t bytes) {
+  if (bytes <= 64 * 1024) return E3_OK;
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, size_t> have;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return E3_ERR_HIP;
+  std::lock_guard<std::mutex> lock(mu);
+  size_t& cur = have[std::make_pair(fn, dev)];
+  if (bytes > cur) {
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return E3_ERR_HIP;
+    cur = bytes;
+  }
+  return E3_OK;
+}
 
 struct TpDev {
   int D1, Dout, Dy, lmax_sh;
@@ -181,7 +201,7 @@ static int tp_launch_fwd(const e3_tp_plan* plan, const void* in1, int64_t ld1, c
   if (smem > 160 * 1024) return E3_ERR_UNSUPPORTED;
   auto kern = tp_fwd_generic_kernel<T, R>;
   if (smem > 64 * 1024)
-    E3_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    { int st_ = tp_ensure_dyn_lds((const void*)kern, smem); if (st_ != E3_OK) return st_; }
   int grid = (int)std::min<int64_t>((B + R - 1) / R, 256 * 8);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, (const T*)in1, ld1, (const T*)in2, ld2, (const A*)packed,
                      (T*)out, ldo, B, plan->dev);
@@ -456,7 +476,7 @@ static int tp_launch_bwd(const e3_tp_plan* plan, const void* in1, int64_t ld1, c
     const size_t lds = (size_t)R * (2 * p.D1 + p.Dy + p.Dout + 9) * sizeof(A);
     if (lds > 160 * 1024) return E3_ERR_UNSUPPORTED;
     auto k = tp_bwd_rows_kernel<T, R>;
-    E3_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    { int st_ = tp_ensure_dyn_lds((const void*)k, lds); if (st_ != E3_OK) return st_; }
     const int grid = (int)std::min<int64_t>((B + R - 1) / R, 256 * 4);
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, (const T*)in1, ld1, (const T*)in2, ld2, (const A*)packed,
                        (const T*)go, ldg, (T*)gin1, ldg1, (A*)gin2, ldg2, B, p);
@@ -469,7 +489,7 @@ static int tp_launch_bwd(const e3_tp_plan* plan, const void* in1, int64_t ld1, c
     const size_t lds = (size_t)RW * (p.D1 + p.Dy + p.Dout) * sizeof(A);
     if (lds > 160 * 1024) return E3_ERR_UNSUPPORTED;
     auto k = tp_bwd_w_kernel<T, RW>;
-    E3_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    { int st_ = tp_ensure_dyn_lds((const void*)k, lds); if (st_ != E3_OK) return st_; }
     const int grid = (int)std::min<int64_t>((B + RW - 1) / RW, 256 * 2);
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, (const T*)in1, ld1, (const T*)in2, ld2, (const A*)packed,
                        (const T*)go, ldg, (A*)gw[0], (A*)gw[1], (A*)gw[2], (A*)gw[3], (A*)gw[4], (A*)gw[5], B, p);
@@ -697,7 +717,7 @@ static int tp_launch_bwd_operands_rw(const e3_tp_plan* plan, const void* in1, in
   const size_t lds = (size_t)R * (p.D1 + p.Dy + p.Dout) * sizeof(A);
   if (lds > 160 * 1024) return E3_ERR_UNSUPPORTED;
   auto k = tp_bwd_operands_kernel<T, RW>;
-  if (lds > 64 * 1024) E3_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if (lds > 64 * 1024) { int st_ = tp_ensure_dyn_lds((const void*)k, lds); if (st_ != E3_OK) return st_; }
   const int grid = (int)std::min<int64_t>((B + R - 1) / R, 256 * 8);
   hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, (const T*)in1, ld1, (const T*)in2, ld2, (const A*)packed,
                      (const T*)go, ldg, f, g, B, p);
@@ -732,7 +752,7 @@ static int tp_launch_bwd_contract_rw(const e3_tp_plan* plan, const void* in1, in
   const size_t lds = tp_bwd_contract_lds<A>(p, R);
   if (lds > 160 * 1024) return E3_ERR_UNSUPPORTED;
   auto k = tp_bwd_contract_kernel<T, RW>;
-  if (lds > 64 * 1024) E3_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if (lds > 64 * 1024) { int st_ = tp_ensure_dyn_lds((const void*)k, lds); if (st_ != E3_OK) return st_; }
   const int grid = (int)std::min<int64_t>((B + R - 1) / R, 256 * 8);
   hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, (const T*)in1, ld1, (const T*)in2, ld2, t, (T*)gin1, ldg1,
                      (A*)gin2, ldg2, B, p);
@@ -1222,7 +1242,7 @@ int e3_tp_backward_weights(const e3_tp_plan* plan, const void* in1, int64_t ld1,
     if (!grad_weights[c]) continue;
     const void* k = ntw[c] <= 2 ? (const void*)tp_wgrad_mfma_kernel<2> : ntw[c] <= 4 ? (const void*)tp_wgrad_mfma_kernel<4>
                   : ntw[c] <= 6 ? (const void*)tp_wgrad_mfma_kernel<6> : (const void*)tp_wgrad_mfma_kernel<8>;
-    E3_HIP_CHECK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds[c]));
+    { int st_ = tp_ensure_dyn_lds(k, lds[c]); if (st_ != E3_OK) return st_; }
     const int64_t ntiles = (B + R[c] - 1) / R[c];
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (size_t)(156 * 1024) / lds[c]));
     const int grid = (int)std::min<int64_t>(ntiles, 256 * per_cu);
