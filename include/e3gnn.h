@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define E3GNN_ABI_VERSION 2
+#define E3GNN_ABI_VERSION 3
 
 /* status codes */
 enum {

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     assert not missing, f"declared in include/*.h but not exported: {missing}"
     assert set(_lib.SIGNATURES) <= set(syms), "python binding lists an undeclared symbol"
     assert set(syms) <= set(_lib.SIGNATURES), f"header symbols without a binding: {set(syms) - set(_lib.SIGNATURES)}"
-    assert lib.e3_abi_version() == 2
+    assert lib.e3_abi_version() == 3
     assert lib.e3_status_string(0) == b"ok"
 
 
