@@ -796,13 +796,15 @@ __device__ __forceinline__ void tp_wgrad_feat_item(const float* x, const float* 
 
 typedef float tp_f32x16 __attribute__((ext_vector_type(16)));
 
-template <int NTW>
+template <int NTW, int RT>
 __global__ __launch_bounds__(256) void tp_wgrad_mfma_kernel(const float* __restrict__ in1, int64_t ld1,
                                                             const float* __restrict__ in2, int64_t ld2,
                                                             const float* __restrict__ packed, const float* __restrict__ go,
-                                                            int64_t ldg, float* __restrict__ gw, int c3, int R, int ldF,
-                                                            int ldG, int64_t B, TpDev p) {
+                                                            int64_t ldg, float* __restrict__ gw, int c3, int ldF, int ldG,
+                                                            int64_t B, TpDev p) {
   using A = float;
+  constexpr int R = RT;
+  constexpr int XC = 3, GC = 2;   // columns of x / (c, w) pairs of G per thread (host: D1 <= 768, D3 M <= 512, RT Dy <= 256)
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int l3 = c3 >> 1, D3 = 2 * l3 + 1, K = p.K[c3], M = p.M[c3];
   float* xs = reinterpret_cast<float*>(smem_raw);
@@ -820,27 +822,62 @@ __global__ __launch_bounds__(256) void tp_wgrad_mfma_kernel(const float* __restr
   // padding columns are zero for the whole launch (the row passes never write them)
   for (int i = tid; i < R * D3 * ldF; i += 256) Fs[i] = 0.f;
   for (int i = tid; i < R * D3 * ldG; i += 256) Gs[i] = 0.f;
-  const int64_t ntiles = (B + R - 1) / R;
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {  // uniform trip count per block: barriers are safe
-    const int64_t row0 = tile * R;
-    __syncthreads();
-    // stage x (class order) and y: column outer, eight rows' loads in flight per thread before their LDS stores (a plain element
-    // loop waited for every load in turn: ~30 us per tile)
-    for (int d = tid; d < p.D1; d += 256) {
-      const int cp = p.cpos[d];
-      for (int r0 = 0; r0 < R; r0 += 8) {
-        float v[8];
+  // this thread's share of a tile's global reads (fixed for the launch): columns tid + 256 j of x, pairs tid + 256 j of G, one y
+  int xcp[XC], gdst[GC], goc[GC];
+  float gnv[GC];
+  const int per = D3 * M;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = row0 + r0 + u < B ? in1[(row0 + r0 + u) * ld1 + d] : 0.f;
+  for (int j = 0; j < XC; ++j) xcp[j] = tid + 256 * j < p.D1 ? p.cpos[tid + 256 * j] : -1;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) xs[(r0 + u) * p.D1 + cp] = v[u];
+  for (int j = 0; j < GC; ++j) {
+    const int e = tid + 256 * j;
+    goc[j] = -1; gdst[j] = 0; gnv[j] = 0.f;
+    if (e < per) {
+      const int c = e / M, w = e - c * M;
+      goc[j] = p.ocol[p.ocol_off[c3] + w] + c;
+      gnv[j] = normcol[goc[j]];
+      gdst[j] = c * ldG + w;
+    }
+  }
+  const int yr_r = tid / p.Dy, yr_d = tid - yr_r * p.Dy;
+  const bool yok = tid < R * p.Dy;
+  // The rows of the NEXT tile travel in registers while this tile is contracted: issued right after the LDS image of the current
+  // tile is complete, stored at the top of the next iteration (the loads of a tile used to be waited for in place)
+  float xr[XC][RT], gr[GC][RT], yr = 0.f;
+  auto issue = [&](const int64_t row0) {
+#pragma unroll
+    for (int j = 0; j < XC; ++j)
+      if (xcp[j] >= 0) {
+#pragma unroll
+        for (int u = 0; u < RT; ++u) xr[j][u] = row0 + u < B ? in1[(row0 + u) * ld1 + tid + 256 * j] : 0.f;
       }
-    }
-    for (int i = tid; i < R * p.Dy; i += 256) {
-      const int r = i / p.Dy, d = i - r * p.Dy;
-      ys[i] = row0 + r < B ? in2[(row0 + r) * ld2 + d] : 0.f;
-    }
+#pragma unroll
+    for (int j = 0; j < GC; ++j)
+      if (goc[j] >= 0) {
+#pragma unroll
+        for (int u = 0; u < RT; ++u) gr[j][u] = row0 + u < B ? go[(row0 + u) * ldg + goc[j]] : 0.f;
+      }
+    if (yok) yr = row0 + yr_r < B ? in2[(row0 + yr_r) * ld2 + yr_d] : 0.f;
+  };
+  const int64_t ntiles = (B + R - 1) / R;
+  if ((int64_t)blockIdx.x < ntiles) issue((int64_t)blockIdx.x * R);
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {  // uniform trip count per block: barriers are safe
+    __syncthreads();   // the previous tile's features / MFMA operands have been read
+#pragma unroll
+    for (int j = 0; j < XC; ++j)
+      if (xcp[j] >= 0) {
+#pragma unroll
+        for (int u = 0; u < RT; ++u) xs[u * p.D1 + xcp[j]] = xr[j][u];
+      }
+#pragma unroll
+    for (int j = 0; j < GC; ++j)
+      if (goc[j] >= 0) {
+#pragma unroll
+        for (int u = 0; u < RT; ++u) Gs[(size_t)u * D3 * ldG + gdst[j]] = gr[j][u] * gnv[j];
+      }
+    if (yok) ys[tid] = yr;
     __syncthreads();
+    if (tile + gridDim.x < ntiles) issue((tile + gridDim.x) * R);
     // features of the tile: wave w owns rows w R/4 .. (w + 1) R/4; a path with n channels puts 64 / np2(n) rows side by side in
     // the 64 lanes (rows past B: x = y = 0 -> zero features)
     {
@@ -860,23 +897,6 @@ __global__ __launch_bounds__(256) void tp_wgrad_mfma_kernel(const float* __restr
                                                                     Fs + (size_t)r * G::D3 * ldF + P.wrow + k, ldF)))
             }
           }
-        }
-      }
-    }
-    // the output gradient of the whole tile, all threads at once: every thread has several independent loads in flight (row by
-    // row inside the wave loop above, each row waited for its own loads: 26 us per tile)
-    {
-      const int per = D3 * M;   // (c, w) pairs of a row
-      for (int e = tid; e < per; e += 256) {
-        const int c = e / M, w = e - c * M;
-        const int oc = p.ocol[p.ocol_off[c3] + w] + c;
-        const float nv = normcol[oc];
-        for (int r0 = 0; r0 < R; r0 += 8) {
-          float v[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) v[u] = row0 + r0 + u < B ? go[(row0 + r0 + u) * ldg + oc] * nv : 0.f;
-#pragma unroll
-          for (int u = 0; u < 8; ++u) Gs[((size_t)(r0 + u) * D3 + c) * ldG + w] = v[u];
         }
       }
     }
@@ -924,10 +944,11 @@ static int tp_wgrad_geometry(const TpDev& p, int c3, int* R, int* ldF, int* ldG,
   auto need_of = [&](int r) {
     return ((size_t)r * p.D1 + (((size_t)r * p.Dy + 3) & ~(size_t)3) + (size_t)r * D3 * (*ldF + *ldG)) * sizeof(float);
   };
-  // several workgroups per CU hide each other's staging loads: the largest row tile that leaves room for four (then two, then one)
-  for (size_t budget : {(size_t)38 * 1024, (size_t)76 * 1024, (size_t)150 * 1024})
-    for (int r : {32, 16, 8})
-      if (need_of(r) <= budget) { *R = r; *lds = need_of(r); return E3_OK; }
+  // per-thread register share of a tile's reads (tp_wgrad_mfma_kernel): 3 columns of x, 2 (c, w) pairs of G, one y
+  if (p.D1 > 768 || D3 * M > 512) return E3_ERR_UNSUPPORTED;
+  for (int r : {16, 8})
+    if (need_of(r) <= (size_t)76 * 1024 && r * p.Dy <= 256) { *R = r; *lds = need_of(r); return E3_OK; }
+  if (need_of(8) <= (size_t)150 * 1024) { *R = 8; *lds = need_of(8); return E3_OK; }
   return E3_ERR_UNSUPPORTED;
 }
 
@@ -1240,17 +1261,20 @@ int e3_tp_backward_weights(const e3_tp_plan* plan, const void* in1, int64_t ld1,
   }
   for (int c = 0; c < 6; ++c) {
     if (!grad_weights[c]) continue;
-    const void* k = ntw[c] <= 2 ? (const void*)tp_wgrad_mfma_kernel<2> : ntw[c] <= 4 ? (const void*)tp_wgrad_mfma_kernel<4>
-                  : ntw[c] <= 6 ? (const void*)tp_wgrad_mfma_kernel<6> : (const void*)tp_wgrad_mfma_kernel<8>;
+    const void* k16 = ntw[c] <= 2 ? (const void*)tp_wgrad_mfma_kernel<2, 16> : ntw[c] <= 4 ? (const void*)tp_wgrad_mfma_kernel<4, 16>
+                    : ntw[c] <= 6 ? (const void*)tp_wgrad_mfma_kernel<6, 16> : (const void*)tp_wgrad_mfma_kernel<8, 16>;
+    const void* k8 = ntw[c] <= 2 ? (const void*)tp_wgrad_mfma_kernel<2, 8> : ntw[c] <= 4 ? (const void*)tp_wgrad_mfma_kernel<4, 8>
+                   : ntw[c] <= 6 ? (const void*)tp_wgrad_mfma_kernel<6, 8> : (const void*)tp_wgrad_mfma_kernel<8, 8>;
+    const void* k = R[c] == 16 ? k16 : k8;
     { int st_ = tp_ensure_dyn_lds(k, lds[c]); if (st_ != E3_OK) return st_; }
     const int64_t ntiles = (B + R[c] - 1) / R[c];
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (size_t)(156 * 1024) / lds[c]));
     const int grid = (int)std::min<int64_t>(ntiles, 256 * per_cu);
     const float* a1 = (const float*)in1; const float* a2 = (const float*)in2; const float* pk = (const float*)packed;
     const float* g = (const float*)grad_out; float* gw = (float*)grad_weights[c];
-    int cc = c, r = R[c], lf = ldF[c], lg = ldG[c];
+    int cc = c, lf = ldF[c], lg = ldG[c];
     TpDev pd = p;
-    void* args[] = {&a1, &ld1, &a2, &ld2, &pk, &g, &ldg, &gw, &cc, &r, &lf, &lg, &B, &pd};
+    void* args[] = {&a1, &ld1, &a2, &ld2, &pk, &g, &ldg, &gw, &cc, &lf, &lg, &B, &pd};
     if (hipLaunchKernel(k, dim3(grid), dim3(256), args, lds[c], s) != hipSuccess) return E3_ERR_HIP;
   }
   return E3_OK;
