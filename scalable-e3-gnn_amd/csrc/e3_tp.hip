@@ -796,6 +796,10 @@ __device__ __forceinline__ void tp_wgrad_feat_item(const float* x, const float* 
 
 typedef float tp_f32x16 __attribute__((ext_vector_type(16)));
 
+// workgroup barrier that orders LDS accesses only: __syncthreads() also waits for every global load in flight (vmcnt(0)), which
+// would end the register prefetch of the next row tile at the first barrier after it was issued
+__device__ __forceinline__ void tp_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <int NTW, int RT>
 __global__ __launch_bounds__(256) void tp_wgrad_mfma_kernel(const float* __restrict__ in1, int64_t ld1,
                                                             const float* __restrict__ in2, int64_t ld2,
@@ -862,7 +866,7 @@ __global__ __launch_bounds__(256) void tp_wgrad_mfma_kernel(const float* __restr
   const int64_t ntiles = (B + R - 1) / R;
   if ((int64_t)blockIdx.x < ntiles) issue((int64_t)blockIdx.x * R);
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {  // uniform trip count per block: barriers are safe
-    __syncthreads();   // the previous tile's features / MFMA operands have been read
+    tp_lds_barrier();   // the previous tile's features / MFMA operands have been read
 #pragma unroll
     for (int j = 0; j < XC; ++j)
       if (xcp[j] >= 0) {
@@ -876,7 +880,7 @@ __global__ __launch_bounds__(256) void tp_wgrad_mfma_kernel(const float* __restr
         for (int u = 0; u < RT; ++u) Gs[(size_t)u * D3 * ldG + gdst[j]] = gr[j][u] * gnv[j];
       }
     if (yok) ys[tid] = yr;
-    __syncthreads();
+    tp_lds_barrier();
     if (tile + gridDim.x < ntiles) issue((tile + gridDim.x) * R);
     // features of the tile: wave w owns rows w R/4 .. (w + 1) R/4; a path with n channels puts 64 / np2(n) rows side by side in
     // the 64 lanes (rows past B: x = y = 0 -> zero features)
@@ -900,7 +904,7 @@ __global__ __launch_bounds__(256) void tp_wgrad_mfma_kernel(const float* __restr
         }
       }
     }
-    __syncthreads();
+    tp_lds_barrier();
     const int kh = lane >> 5, i32 = lane & 31;
     const int nk = R * D3;  // k rows of this tile (even: R is a multiple of 2)
 #pragma unroll
