@@ -815,9 +815,17 @@ __global__ __launch_bounds__(256) void tp_wgrad_mfma_kernel(const float* __restr
   float* ys = xs + (size_t)R * p.D1;
   float* Fs = ys + (((size_t)R * p.Dy + 3) & ~(size_t)3);
   float* Gs = Fs + (size_t)R * D3 * ldF;
+  // the class's path descriptors in LDS (l1, l2, wrow, n, cbase): a GLOBAL read inside the tile loop is followed by vmcnt(0), which
+  // would also wait for the whole register prefetch issued just before it
+  int* ptab = reinterpret_cast<int*>(Gs + (size_t)R * D3 * ldG);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const float* normcol = packed + p.normcol_off;
   const int tm = (K + 31) / 32, tn = (M + 31) / 32, ntile = tm * tn;
+  const int npath = p.npath[c3];
+  if (tid < npath) {
+    const TpPath P = p.paths[p.poff[c3] + tid];
+    ptab[8 * tid] = P.l1; ptab[8 * tid + 1] = P.l2; ptab[8 * tid + 2] = P.wrow; ptab[8 * tid + 3] = p.n[P.c1]; ptab[8 * tid + 4] = p.cbase[P.c1];
+  }
   tp_f32x16 acc[NTW];
 #pragma unroll
   for (int t = 0; t < NTW; ++t)
@@ -886,9 +894,10 @@ __global__ __launch_bounds__(256) void tp_wgrad_mfma_kernel(const float* __restr
     // the 64 lanes (rows past B: x = y = 0 -> zero features)
     {
       const int rw = R >> 2, rbase = wave * rw;
-      for (int pi = 0; pi < p.npath[c3]; ++pi) {
-        const TpPath P = p.paths[p.poff[c3] + pi];
-        const int n = p.n[P.c1];
+      for (int pi = 0; pi < npath; ++pi) {
+        const int Pl1 = __builtin_amdgcn_readfirstlane(ptab[8 * pi]), Pl2 = __builtin_amdgcn_readfirstlane(ptab[8 * pi + 1]);
+        const int Pwrow = __builtin_amdgcn_readfirstlane(ptab[8 * pi + 2]), n = __builtin_amdgcn_readfirstlane(ptab[8 * pi + 3]);
+        const int Pcb = __builtin_amdgcn_readfirstlane(ptab[8 * pi + 4]);
         int sh = 6;                                   // np2 = 1 << sh >= n, at most 64
         while (sh > 0 && (1 << (sh - 1)) >= n) --sh;
         const int np2 = 1 << sh, rpi = 64 >> sh, sub = lane >> sh, k0 = lane & (np2 - 1);
@@ -896,9 +905,9 @@ __global__ __launch_bounds__(256) void tp_wgrad_mfma_kernel(const float* __restr
           const int r = rbase + rb + sub;
           for (int k = k0; k < n; k += np2) {   // (one trip unless n > 64)
             if (rb + sub < rw) {
-              E3_GRAD_SWITCH(P.l1, P.l2, l3, (tp_wgrad_feat_item<G>(xs + r * p.D1 + p.cbase[P.c1] + k * G::D1,
-                                                                    ys + r * p.Dy + G::D2 / 2 * (G::D2 / 2),
-                                                                    Fs + (size_t)r * G::D3 * ldF + P.wrow + k, ldF)))
+              E3_GRAD_SWITCH(Pl1, Pl2, l3, (tp_wgrad_feat_item<G>(xs + r * p.D1 + Pcb + k * G::D1,
+                                                                  ys + r * p.Dy + G::D2 / 2 * (G::D2 / 2),
+                                                                  Fs + (size_t)r * G::D3 * ldF + Pwrow + k, ldF)))
             }
           }
         }
@@ -946,10 +955,10 @@ static int tp_wgrad_geometry(const TpDev& p, int c3, int* R, int* ldF, int* ldG,
   *ntw = (ntile + 3) / 4;
   if (*ntw > 8) return E3_ERR_UNSUPPORTED;
   auto need_of = [&](int r) {
-    return ((size_t)r * p.D1 + (((size_t)r * p.Dy + 3) & ~(size_t)3) + (size_t)r * D3 * (*ldF + *ldG)) * sizeof(float);
+    return ((size_t)r * p.D1 + (((size_t)r * p.Dy + 3) & ~(size_t)3) + (size_t)r * D3 * (*ldF + *ldG)) * sizeof(float) + 64 * 8 * sizeof(int);
   };
   // per-thread register share of a tile's reads (tp_wgrad_mfma_kernel): 3 columns of x, 2 (c, w) pairs of G, one y
-  if (p.D1 > 768 || D3 * M > 512) return E3_ERR_UNSUPPORTED;
+  if (p.D1 > 768 || D3 * M > 512 || p.npath[c3] > 64) return E3_ERR_UNSUPPORTED;
   for (int r : {16, 8})
     if (need_of(r) <= (size_t)76 * 1024 && r * p.Dy <= 256) { *R = r; *lds = need_of(r); return E3_OK; }
   if (need_of(8) <= (size_t)150 * 1024) { *R = 8; *lds = need_of(8); return E3_OK; }

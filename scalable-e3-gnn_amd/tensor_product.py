@@ -234,7 +234,7 @@ _BWD_GEMM_MIN_ROWS = 512
 
 _WGRAD_SLAB = 4096
 # grad_W alone (no grad_in1 / grad_in2 wanted from this call) through e3_tp_backward_weights: features in LDS + fp32 MFMA, nothing
-# of size [B, D3, K] in HBM (109 vs 134 ms for the 100 k-particle forward + backward).  False: always the operand pass + batched
+# of size [B, D3, K] in HBM (106 vs 134 ms for the 100 k-particle forward + backward).  False: always the operand pass + batched
 # GEMM (tests/test_tp_backward_gpu.py compares the two)
 _BWD_FUSED_WGRAD = True
 
