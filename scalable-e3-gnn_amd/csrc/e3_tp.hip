@@ -857,6 +857,22 @@ __global__ __launch_bounds__(256) void tp_wgrad_mfma_kernel(const float* __restr
   // tile is complete, stored at the top of the next iteration (the loads of a tile used to be waited for in place)
   float xr[XC][RT], gr[GC][RT], yr = 0.f;
   auto issue = [&](const int64_t row0) {
+    if (row0 + RT <= B) {   // whole tile inside the batch (every tile but the last): no per-row predicate, i.e. no branch per load
+#pragma unroll
+      for (int j = 0; j < XC; ++j)
+        if (xcp[j] >= 0) {
+#pragma unroll
+          for (int u = 0; u < RT; ++u) xr[j][u] = in1[(row0 + u) * ld1 + tid + 256 * j];
+        }
+#pragma unroll
+      for (int j = 0; j < GC; ++j)
+        if (goc[j] >= 0) {
+#pragma unroll
+          for (int u = 0; u < RT; ++u) gr[j][u] = go[(row0 + u) * ldg + goc[j]];
+        }
+      if (yok) yr = in2[(row0 + yr_r) * ld2 + yr_d];
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < XC; ++j)
       if (xcp[j] >= 0) {
